@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Throughput of the batched AL-iLQR solve path on MI355X.
+
+One "step" = one complete solve of the workload batch: 4096 lateral-bicycle
+problems (H=50, box-constrained, start states randomised with seed = rank), the
+configuration BASELINE.json quotes the solves/sec metric on.  Inputs are
+resident in HBM before the timed region; every rank owns its own batch (weak
+scaling, no collective inside the solve; the per-step gather of the cost vector
+over RCCL is the only exchange).
+
+  python bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from ilqr_amd import batch, capi, problems  # noqa: E402
+
+# Algorithmic fp64 operation counts per node (lateral model), dense as the
+# reference computes them; a transcendental call is counted as ONE operation.
+LAT_FLOPS = dict(bwd=469, lin=60 + 4, quad=40, dyn=30 + 6, cost=60)
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector fp64 (half the 157.3 TF fp32 vector rate)
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_flops(status, H):
+    n_inner = status[:, 0].astype(np.float64).sum()
+    n_trials = status[:, 3].astype(np.float64).sum()
+    f = LAT_FLOPS
+    return n_inner * H * (f["lin"] + f["quad"] + f["bwd"]) + n_trials * (H * f["dyn"] + (H + 1) * f["cost"])
+
+
+def algorithmic_bytes(desc):
+    B, H, n, m = desc.batch, desc.horizon, desc.n, desc.m
+    return 8.0 * B * (n + (H + 1) * n + H * m + 1) + 16.0 * B
+
+
+def cpu_baseline(sample, seconds_hint=20.0):
+    """The CPU oracle (a restatement of the reference, 'port') on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    threads = max(1, min(16, os.cpu_count() or 1, oracle_lib.lib().oracle_max_threads()))
+    desc, x0, goals, Q, R, cons = problems.lat_legacy(sample, 50, seed=0)
+    t0 = time.perf_counter()
+    oracle_lib.solve_batch(desc, x0, goals, Q, R, cons, threads=threads, extras=False)
+    dt = time.perf_counter() - t0
+    return dict(value=sample / dt, unit="solves/s", cores=threads, kind="port",
+                sample=f"first {sample} problems of the same 4096-problem batch, OpenMP over problems, {dt:.2f} s wall")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, H = args.batch, 50
+    desc, x0, goals, Q, R, cons = problems.lat_legacy(B, H, seed=rank)
+    solver = batch.BatchSolver(desc, x0, goals, Q, R, cons, extras=False, device=dev)
+    gathered = torch.empty((world * B,), dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step():
+        out = solver.run()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out["cost"])
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        out = step()
+        ev[k][1].record()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    status = out["status"].cpu().numpy()
+    cost = out["cost"].cpu().numpy()
+    flops = algorithmic_flops(status, H)
+    tf = flops / (kernel_ms * 1e-3) / 1e12
+    hit_cap = float(np.mean((status[:, 2] & capi.FLAG_OUTER_CAP) != 0))
+
+    if rank == 0:
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as fh:
+                    traffic = json.load(fh).get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        line = {
+            "metric": "converged AL-iLQR solves/sec (H=50, batch N)",
+            "value": world * B * args.steps / dt,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "lat-bicycle AL-iLQR (ILQR + LatBicycleKinematicNode, box constraints), H=50, "
+                                   f"batch {B} per GPU, start states x0=(0,U(-1,1),U(-0.2,0.2),U(-0.05,0.05)) seed=rank",
+                       "batch_per_gpu": B, "horizon": H, "mode": "legacy", "model": "lat",
+                       "lanes_per_problem": os.environ.get("ALILQR_LANES", "auto"),
+                       "mean_inner_iters": float(status[:, 0].mean()), "mean_rollouts": float(status[:, 3].mean()),
+                       "frac_outer_cap": hit_cap, "frac_nonfinite": float(np.mean(~np.isfinite(cost)))},
+            "roofline": {"bound": "valu_fp64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "alilqr::solve_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_flops_per_launch": flops,
+                         "algorithmic_hbm_bytes_per_launch": algorithmic_bytes(desc),
+                         "hbm_GBs_algorithmic": algorithmic_bytes(desc) / (kernel_ms * 1e-3) / 1e9,
+                         "hbm_peak_GBs": HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+"""Batched solve / node-evaluation entry points over the C ABI.
+
+torch-ROCm tensors own the device buffers and give the stream; all compute is
+in libalilqr_hip.so.  There is no CPU path: without the library or a GPU these
+functions raise.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _dev_f64(a, device):
+    torch = _torch()
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=torch.float64).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=device)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _require_gpu(device):
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError("ilqr_amd needs a HIP device: torch.cuda.is_available() is False "
+                           "(there is no CPU fallback for the solve path)")
+    return torch.device(device)
+
+
+def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=True):
+    """Solve ``desc.batch`` problems on the GPU.
+
+    Inputs may be numpy arrays or torch tensors (moved to ``device`` as fp64):
+      x0 [B,n], goals [goal_batch,H+1,n], Q [T,n,n], R [T,m,m], cons [T,words].
+    Returns a dict of device tensors: x [B,H+1,n], u [B,H,m], cost [B] and, with
+    ``extras``, node_x, node_u, x_init, u_init, viol, lam, mu, status.
+    """
+    torch = _torch()
+    lib = capi.load_library()
+    dev = _require_gpu(device)
+    B, H, n, m, c = desc.batch, desc.horizon, desc.n, desc.m, desc.c
+    x0_d, goals_d, Q_d, R_d, cons_d = (_dev_f64(a, dev) for a in (x0, goals, Q, R, cons))
+    if x0_d.numel() != B * n:
+        raise ValueError(f"x0 has {x0_d.numel()} values, expected batch*n = {B * n}")
+    if goals_d.numel() != desc.goal_batch * (H + 1) * n:
+        raise ValueError("goals must hold goal_batch*(H+1)*n values")
+    if Q_d.numel() != desc.table_nodes * n * n or R_d.numel() != desc.table_nodes * m * m:
+        raise ValueError("Q / R must hold table_nodes matrices")
+    if cons_d.numel() != desc.table_nodes * capi.cons_words(desc):
+        raise ValueError("constraint table has the wrong size")
+    f64 = dict(dtype=torch.float64, device=dev)
+    out = dict(x=torch.empty((B, H + 1, n), **f64), u=torch.empty((B, H, m), **f64), cost=torch.empty((B,), **f64))
+    if extras:
+        out.update(node_x=torch.empty((B, H + 1, n), **f64), node_u=torch.empty((B, H, m), **f64),
+                   x_init=torch.empty((B, H + 1, n), **f64), u_init=torch.empty((B, H, m), **f64),
+                   viol=torch.empty((B,), **f64), lam=torch.empty((B, H + 1, c), **f64), mu=torch.empty((B,), **f64),
+                   status=torch.zeros((B, capi.STATUS_WORDS), dtype=torch.int32, device=dev))
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.alilqr_solve_batch(C.byref(desc), _ptr(x0_d), _ptr(goals_d), _ptr(Q_d), _ptr(R_d), _ptr(cons_d),
+                                    _ptr(out["x"]), _ptr(out["u"]), _ptr(out.get("node_x")), _ptr(out.get("node_u")),
+                                    _ptr(out.get("x_init")), _ptr(out.get("u_init")), _ptr(out["cost"]),
+                                    _ptr(out.get("viol")), _ptr(out.get("lam")), _ptr(out.get("mu")),
+                                    _ptr(out.get("status")), C.c_void_p(stream))
+        capi.check(rc, "alilqr_solve_batch")
+        if sync:
+            torch.cuda.synchronize(dev)
+    return out
+
+
+class BatchSolver:
+    """Inputs resident in HBM, outputs pre-allocated: ``run()`` only enqueues the solve."""
+
+    def __init__(self, desc, x0, goals, Q, R, cons, extras=False, device="cuda:0"):
+        torch = _torch()
+        self.lib = capi.load_library()
+        self.dev = _require_gpu(device)
+        self.desc = desc
+        B, H, n, m, c = desc.batch, desc.horizon, desc.n, desc.m, desc.c
+        self.inputs = [_dev_f64(a, self.dev) for a in (x0, goals, Q, R, cons)]
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        self.out = dict(x=torch.empty((B, H + 1, n), **f64), u=torch.empty((B, H, m), **f64),
+                        cost=torch.empty((B,), **f64),
+                        status=torch.zeros((B, capi.STATUS_WORDS), dtype=torch.int32, device=self.dev))
+        if extras:
+            self.out.update(node_x=torch.empty((B, H + 1, n), **f64), node_u=torch.empty((B, H, m), **f64),
+                            viol=torch.empty((B,), **f64), mu=torch.empty((B,), **f64))
+
+    def run(self, stream_ptr=None):
+        torch = _torch()
+        if stream_ptr is None:
+            stream_ptr = torch.cuda.current_stream(self.dev).cuda_stream
+        o = self.out
+        rc = self.lib.alilqr_solve_batch(C.byref(self.desc), *[_ptr(t) for t in self.inputs],
+                                         _ptr(o["x"]), _ptr(o["u"]), _ptr(o.get("node_x")), _ptr(o.get("node_u")),
+                                         None, None, _ptr(o["cost"]), _ptr(o.get("viol")), None, _ptr(o.get("mu")),
+                                         _ptr(o["status"]), C.c_void_p(stream_ptr))
+        capi.check(rc, "alilqr_solve_batch")
+        return o
+
+
+def linearize_batch(desc, x, u, lam, mu, goals, Q, R, cons, device="cuda:0"):
+    """Evaluate f, f_x, f_u, l, l_x, l_u, l_xx, l_uu on B*(H+1) nodes in parallel."""
+    torch = _torch()
+    lib = capi.load_library()
+    dev = _require_gpu(device)
+    B, H, n, m = desc.batch, desc.horizon, desc.n, desc.m
+    ins = [_dev_f64(a, dev) for a in (x, u, lam, mu, goals, Q, R, cons)]
+    f64 = dict(dtype=torch.float64, device=dev)
+    out = dict(f=torch.empty((B, H + 1, n), **f64), fx=torch.empty((B, H + 1, n, n), **f64),
+               fu=torch.empty((B, H + 1, n, m), **f64), l=torch.empty((B, H + 1), **f64),
+               lx=torch.empty((B, H + 1, n), **f64), lu=torch.empty((B, H + 1, m), **f64),
+               lxx=torch.empty((B, H + 1, n, n), **f64), luu=torch.empty((B, H + 1, m, m), **f64))
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.alilqr_linearize_batch(C.byref(desc), *[_ptr(t) for t in ins],
+                                        *[_ptr(out[k]) for k in ("f", "fx", "fu", "l", "lx", "lu", "lxx", "luu")],
+                                        C.c_void_p(stream))
+        capi.check(rc, "alilqr_linearize_batch")
+        torch.cuda.synchronize(dev)
+    return out

@@ -1,0 +1,365 @@
+// alilqr_api.hip — C ABI of the batched AL-iLQR solve path (see include/alilqr.h).
+//
+// Host side: argument checks, workspace, lane-group width selection, launch.
+// No CPU compute path exists here: without a GPU every compute entry point
+// returns ALILQR_E_NODEVICE / ALILQR_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/alilqr.h"
+#include "solver.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+void set_err(const char* fmt, const char* a = "", const char* b = "") {
+  std::snprintf(g_err, sizeof(g_err), fmt, a, b);
+}
+
+#define HIP_TRY(call)                                                        \
+  do {                                                                       \
+    hipError_t e_ = (call);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      set_err("%s: %s", #call, hipGetErrorString(e_));                       \
+      return ALILQR_E_HIP;                                                   \
+    }                                                                        \
+  } while (0)
+
+// grow-only device scratch, one per device
+struct Workspace {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+};
+constexpr int kMaxDev = 16;
+Workspace g_ws[kMaxDev];
+std::mutex g_mu;
+
+struct Dims {
+  int N, M, NA, NB, E;
+};
+
+bool model_dims(int model, Dims* d) {
+  using namespace alilqr;
+  switch (model) {
+    case ALILQR_MODEL_LAT: *d = {4, 1, Model<ALILQR_MODEL_LAT>::NA, Model<ALILQR_MODEL_LAT>::NB, LinLayout<Model<ALILQR_MODEL_LAT>>::E}; return true;
+    case ALILQR_MODEL_KIN:
+    case ALILQR_MODEL_DYN:
+    case ALILQR_MODEL_DYN_MID: *d = {6, 2, Model<ALILQR_MODEL_KIN>::NA, Model<ALILQR_MODEL_KIN>::NB, LinLayout<Model<ALILQR_MODEL_KIN>>::E}; return true;
+    default: return false;
+  }
+}
+
+int32_t check_problem(const alilqr_problem* p, Dims* d) {
+  if (!p) { set_err("null problem descriptor"); return ALILQR_E_ARG; }
+  if (p->abi_version != ALILQR_ABI_VERSION) { set_err("descriptor abi_version mismatch"); return ALILQR_E_ARG; }
+  if (!model_dims(p->model, d)) { set_err("unsupported model"); return ALILQR_E_ARG; }
+  if (p->n != d->N || p->m != d->M) { set_err("n/m do not match the model"); return ALILQR_E_ARG; }
+  if (p->horizon < 1 || p->batch < 0) { set_err("horizon must be >= 1 and batch >= 0"); return ALILQR_E_ARG; }
+  if (p->goal_batch != 1 && p->goal_batch != p->batch) { set_err("goal_batch must be 1 or batch"); return ALILQR_E_ARG; }
+  if (p->table_nodes != 1 && p->table_nodes != p->horizon + 1) { set_err("table_nodes must be 1 or horizon+1"); return ALILQR_E_ARG; }
+  if (p->mode == ALILQR_MODE_LEGACY) {
+    if (p->c != 2 * (p->n + p->m)) { set_err("LEGACY needs c = 2(n+m)"); return ALILQR_E_ARG; }
+    if (p->model == ALILQR_MODEL_DYN_MID) { set_err("LEGACY is defined for LAT, KIN, DYN"); return ALILQR_E_ARG; }
+  } else if (p->mode == ALILQR_MODE_FAST) {
+    if (p->c < 1 || p->c > 64) { set_err("FAST needs 1 <= c <= 64"); return ALILQR_E_ARG; }
+    if (p->model != ALILQR_MODEL_DYN_MID) { set_err("FAST is defined for DYN_MID"); return ALILQR_E_ARG; }
+  } else {
+    set_err("unsupported solver mode"); return ALILQR_E_ARG;
+  }
+  if (p->prm.max_outer < 1 || p->prm.max_inner < 1 || !(p->prm.alpha_min > 0.0)) {
+    set_err("max_outer, max_inner must be >= 1 and alpha_min > 0"); return ALILQR_E_ARG;
+  }
+  return ALILQR_OK;
+}
+
+// lanes per problem: enough lanes to put every line-search trial of the
+// reference in flight, unless the batch alone already fills the machine
+int pick_group(const alilqr_problem* p) {
+  if (const char* e = std::getenv("ALILQR_LANES")) {
+    int g = std::atoi(e);
+    if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32) return g;
+  }
+  const long target_waves = 2048;   // 2 waves on each of the 1024 SIMDs
+  for (int g : {32, 8}) {
+    if ((long)p->batch * g / 64 <= target_waves) return g;
+  }
+  return 1;
+}
+
+struct Plan {
+  int G, NG;
+  size_t trj, kk, lin, lam, counter, total;   // byte offsets / total
+};
+
+Plan make_plan(const alilqr_problem* p, const Dims& d) {
+  Plan pl{};
+  pl.G = pick_group(p);
+  long max_waves = 4096;
+  if (const char* e = std::getenv("ALILQR_MAX_WAVES")) { long w = std::atol(e); if (w > 0) max_waves = w; }
+  long gpw = 64 / pl.G;                             // groups per wave
+  long need_waves = ((long)p->batch + gpw - 1) / gpw;
+  long waves = need_waves < max_waves ? need_waves : max_waves;
+  if (waves < 1) waves = 1;
+  pl.NG = (int)(waves * gpw);
+  const size_t H = p->horizon, N = d.N, M = d.M;
+  const size_t T = (H + 1) * N + H * M;
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t off = 0;
+  pl.counter = off; off = up(off + 256);
+  pl.trj = off; off = up(off + sizeof(double) * 2 * T * (size_t)pl.NG * pl.G);
+  pl.kk = off; off = up(off + sizeof(double) * H * (M * N + M) * (size_t)pl.NG);
+  pl.lin = off; off = up(off + sizeof(double) * (H + 1) * d.E * (size_t)pl.NG);
+  pl.lam = off; off = up(off + sizeof(double) * (H + 1) * (size_t)p->c * (size_t)pl.NG);
+  pl.total = off;
+  return pl;
+}
+
+template <int MODEL, int MODE>
+int32_t launch_g(const alilqr::KArgs& ka, int G, int waves, hipStream_t st) {
+  dim3 grid(waves), block(64);
+  switch (G) {
+    case 1: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 1>), grid, block, 0, st, ka); break;
+    case 2: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 2>), grid, block, 0, st, ka); break;
+    case 4: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 4>), grid, block, 0, st, ka); break;
+    case 8: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 8>), grid, block, 0, st, ka); break;
+    case 16: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 16>), grid, block, 0, st, ka); break;
+    case 32: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 32>), grid, block, 0, st, ka); break;
+    default: set_err("bad lane-group width"); return ALILQR_E_ARG;
+  }
+  HIP_TRY(hipGetLastError());
+  return ALILQR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// node evaluation kernel (alilqr_linearize_batch): one thread per node
+// ---------------------------------------------------------------------------
+struct LArgs {
+  int B, H, C, goal_batch, table_nodes;
+  alilqr::ModelConst mc;
+  const double *x, *u, *lam, *mu, *goals, *Q, *R, *cons;
+  double *f, *fx, *fu, *l, *lx, *lu, *lxx, *luu;
+};
+
+template <int MODEL, int MODE>
+__global__ __launch_bounds__(256) void linearize_kernel(LArgs a) {
+  using namespace alilqr;
+  using MD = Model<MODEL>;
+  using OPS = NodeOps<MODEL, MODE>;
+  using LL = LinLayout<MD>;
+  constexpr int N = MD::N, M = MD::M;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)a.B * (a.H + 1);
+  if (i >= total) return;
+  const int b = (int)(i / (a.H + 1)), t = (int)(i % (a.H + 1));
+  const int tt = (a.table_nodes > 1) ? t : 0;
+  const int cw = (MODE == ALILQR_MODE_LEGACY) ? (2 * N + 2 * M) : a.C * (N + M + 1);
+  KArgs ka{};
+  ka.C = a.C;
+  double x[N], u[M], xn[N], ac[MD::NA], bc[MD::NB], S[N][N], Bm[N][M];
+#pragma unroll
+  for (int q = 0; q < N; ++q) x[q] = a.x[i * N + q];
+#pragma unroll
+  for (int q = 0; q < M; ++q) u[q] = a.u[i * M + q];
+  MD::step(a.mc, x, u, xn);
+  MD::jac(a.mc, x, u, ac, bc);
+  expand_jac<MD>(a.mc, ac, bc, S, Bm);
+  // the node keeps its state angle-wrapped from its first cost call on
+  x[2] = wrap_py(x[2]);
+  x[3] = wrap_py(x[3]);
+  const double* g = a.goals + ((a.goal_batch > 1) ? (size_t)b * (a.H + 1) * N : 0) + (size_t)t * N;
+  const double* Q = a.Q + (size_t)tt * N * N;
+  const double* R = a.R + (size_t)tt * M * M;
+  const double* tab = a.cons + (size_t)tt * cw;
+  const double* lam = a.lam + i * a.C;
+  const double mu = a.mu[b];
+  double rec[LL::E];
+  double cost = OPS::cost(ka, Q, R, tab, x, u, g, lam, 1, mu);
+  OPS::quadratize(ka, Q, R, tab, x, u, g, lam, 1, mu, rec, 1);
+  if (a.f) for (int q = 0; q < N; ++q) a.f[i * N + q] = xn[q];
+  if (a.fx)
+    for (int r = 0; r < N; ++r)
+      for (int q = 0; q < N; ++q) a.fx[(i * N + r) * N + q] = ((r == q) ? 1.0 : 0.0) + S[r][q];
+  if (a.fu)
+    for (int r = 0; r < N; ++r)
+      for (int q = 0; q < M; ++q) a.fu[(i * N + r) * M + q] = Bm[r][q];
+  if (a.l) a.l[i] = cost;
+  if (a.lx) for (int q = 0; q < N; ++q) a.lx[i * N + q] = rec[LL::oLx + q];
+  if (a.lu) for (int q = 0; q < M; ++q) a.lu[i * M + q] = rec[LL::oLu + q];
+  if (a.lxx) for (int q = 0; q < N * N; ++q) a.lxx[i * N * N + q] = rec[LL::oLxx + q];
+  if (a.luu) for (int q = 0; q < M * M; ++q) a.luu[i * M * M + q] = rec[LL::oLuu + q];
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t alilqr_abi_version(void) { return ALILQR_ABI_VERSION; }
+
+const char* alilqr_last_error(void) { return g_err; }
+
+int32_t alilqr_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { set_err("hipGetDeviceCount: %s", hipGetErrorString(e)); return ALILQR_E_NODEVICE; }
+  return n;
+}
+
+int32_t alilqr_default_params(int32_t mode, alilqr_params* out) {
+  if (!out) { set_err("null params"); return ALILQR_E_ARG; }
+  alilqr_params p{};
+  p.init_r = 20.0;
+  p.dv_gate = 0.2;
+  p.alpha_min = 1e-8;
+  switch (mode) {
+    case ALILQR_MODE_LEGACY:
+      p.max_outer = 20; p.max_inner = 20; p.inner_tol = 1e-8; p.viol_stop = 1e-3; p.viol_lambda = 1e-1;
+      p.mu_gain = 8.0; p.quu_reg = 1e-9; break;
+    case ALILQR_MODE_FAST:
+      p.max_outer = 20; p.max_inner = 20; p.inner_tol = 1e-8; p.viol_stop = 1e-3; p.viol_lambda = 1e-1;
+      p.mu_gain = 8.0; p.quu_reg = 0.0; break;
+    case ALILQR_MODE_NEW_AL:
+      p.max_outer = 50; p.max_inner = 100; p.inner_tol = 1e-3; p.viol_stop = 1e-4; p.viol_lambda = 5e-4;
+      p.mu_gain = 100.0; p.quu_reg = 0.0; break;
+    default: set_err("unknown solver mode"); return ALILQR_E_ARG;
+  }
+  *out = p;
+  return ALILQR_OK;
+}
+
+int64_t alilqr_workspace_bytes(const alilqr_problem* p) {
+  Dims d;
+  int32_t rc = check_problem(p, &d);
+  if (rc != ALILQR_OK) return rc;
+  return (int64_t)make_plan(p, d).total;
+}
+
+int32_t alilqr_solve_batch(const alilqr_problem* p,
+                           const double* x0, const double* goals,
+                           const double* Q, const double* R, const double* cons,
+                           double* x_out, double* u_out,
+                           double* node_x, double* node_u,
+                           double* x_init, double* u_init,
+                           double* cost, double* viol,
+                           double* lam, double* mu,
+                           int32_t* status, void* stream) {
+  Dims d;
+  int32_t rc = check_problem(p, &d);
+  if (rc != ALILQR_OK) return rc;
+  if (!x0 || !goals || !Q || !R || !cons || !x_out || !u_out || !cost) {
+    set_err("x0, goals, Q, R, cons, x_out, u_out, cost must not be null");
+    return ALILQR_E_ARG;
+  }
+  if (p->batch == 0) return ALILQR_OK;
+  int dev = 0;
+  {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { set_err("no HIP device is visible"); return ALILQR_E_NODEVICE; }
+  }
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDev) { set_err("device index out of range"); return ALILQR_E_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  Plan pl = make_plan(p, d);
+  char* base = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Workspace& w = g_ws[dev];
+    if (w.bytes < pl.total) {
+      if (w.ptr) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(w.ptr)); w.ptr = nullptr; w.bytes = 0; }
+      hipError_t e = hipMalloc(&w.ptr, pl.total);
+      if (e != hipSuccess) { set_err("hipMalloc(workspace): %s", hipGetErrorString(e)); w.ptr = nullptr; return ALILQR_E_NOMEM; }
+      w.bytes = pl.total;
+    }
+    base = (char*)w.ptr;
+  }
+  HIP_TRY(hipMemsetAsync(base + pl.counter, 0, 256, st));
+
+  alilqr::KArgs ka{};
+  ka.B = p->batch; ka.NG = pl.NG; ka.H = p->horizon; ka.C = p->c;
+  ka.goal_batch = p->goal_batch; ka.table_nodes = p->table_nodes;
+  ka.mc = {p->L, p->dt, p->v, p->k};
+  ka.prm = p->prm;
+  ka.x0 = x0; ka.goals = goals; ka.Q = Q; ka.R = R; ka.cons = cons;
+  ka.x_out = x_out; ka.u_out = u_out; ka.node_x = node_x; ka.node_u = node_u;
+  ka.x_init = x_init; ka.u_init = u_init; ka.cost = cost; ka.viol = viol; ka.lam = lam; ka.mu = mu;
+  ka.status = status;
+  ka.trj = (double*)(base + pl.trj); ka.kk = (double*)(base + pl.kk);
+  ka.lin = (double*)(base + pl.lin); ka.lamw = (double*)(base + pl.lam);
+  ka.counter = (unsigned int*)(base + pl.counter);
+  const int waves = pl.NG * pl.G / 64;
+
+  if (p->mode == ALILQR_MODE_LEGACY) {
+    switch (p->model) {
+      case ALILQR_MODEL_LAT: return launch_g<ALILQR_MODEL_LAT, ALILQR_MODE_LEGACY>(ka, pl.G, waves, st);
+      case ALILQR_MODEL_KIN: return launch_g<ALILQR_MODEL_KIN, ALILQR_MODE_LEGACY>(ka, pl.G, waves, st);
+      case ALILQR_MODEL_DYN: return launch_g<ALILQR_MODEL_DYN, ALILQR_MODE_LEGACY>(ka, pl.G, waves, st);
+      default: break;
+    }
+  } else if (p->mode == ALILQR_MODE_FAST) {
+    if (p->model == ALILQR_MODEL_DYN_MID) return launch_g<ALILQR_MODEL_DYN_MID, ALILQR_MODE_FAST>(ka, pl.G, waves, st);
+  }
+  set_err("unsupported model / mode combination");
+  return ALILQR_E_ARG;
+}
+
+int32_t alilqr_linearize_batch(const alilqr_problem* p,
+                               const double* x, const double* u,
+                               const double* lam, const double* mu,
+                               const double* goals, const double* Q, const double* R, const double* cons,
+                               double* f, double* fx, double* fu, double* l,
+                               double* lx, double* lu, double* lxx, double* luu,
+                               void* stream) {
+  Dims d;
+  int32_t rc = check_problem(p, &d);
+  if (rc != ALILQR_OK) return rc;
+  if (!x || !u || !lam || !mu || !goals || !Q || !R || !cons) { set_err("null input"); return ALILQR_E_ARG; }
+  if (p->batch == 0) return ALILQR_OK;
+  {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { set_err("no HIP device is visible"); return ALILQR_E_NODEVICE; }
+  }
+  LArgs a{};
+  a.B = p->batch; a.H = p->horizon; a.C = p->c; a.goal_batch = p->goal_batch; a.table_nodes = p->table_nodes;
+  a.mc = {p->L, p->dt, p->v, p->k};
+  a.x = x; a.u = u; a.lam = lam; a.mu = mu; a.goals = goals; a.Q = Q; a.R = R; a.cons = cons;
+  a.f = f; a.fx = fx; a.fu = fu; a.l = l; a.lx = lx; a.lu = lu; a.lxx = lxx; a.luu = luu;
+  const size_t total = (size_t)p->batch * (p->horizon + 1);
+  dim3 block(256), grid((unsigned)((total + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (p->mode == ALILQR_MODE_LEGACY) {
+    switch (p->model) {
+      case ALILQR_MODEL_LAT: hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_LAT, ALILQR_MODE_LEGACY>), grid, block, 0, st, a); break;
+      case ALILQR_MODEL_KIN: hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_KIN, ALILQR_MODE_LEGACY>), grid, block, 0, st, a); break;
+      case ALILQR_MODEL_DYN: hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_DYN, ALILQR_MODE_LEGACY>), grid, block, 0, st, a); break;
+      default: set_err("unsupported model / mode combination"); return ALILQR_E_ARG;
+    }
+  } else {
+    hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_DYN_MID, ALILQR_MODE_FAST>), grid, block, 0, st, a);
+  }
+  HIP_TRY(hipGetLastError());
+  return ALILQR_OK;
+}
+
+int32_t alilqr_release(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < kMaxDev; ++i) {
+    if (g_ws[i].ptr) {
+      int cur = 0;
+      if (hipGetDevice(&cur) == hipSuccess) {
+        (void)hipSetDevice(i);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(g_ws[i].ptr);
+        (void)hipSetDevice(cur);
+      }
+      g_ws[i].ptr = nullptr;
+      g_ws[i].bytes = 0;
+    }
+  }
+  return ALILQR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,229 @@
+// models.hpp — bicycle models of the solve path for gfx950 (fp64, one value per lane).
+//
+// Each model gives the RK2-midpoint step x+ = f(x,u) and the closed-form
+// Jacobian of that step.  The Jacobian is I + a few entries; only the entries
+// that vary are produced ("compact" form) and the structural pattern is
+// constexpr so that the Riccati code, once unrolled, touches non-zeros only.
+//
+// The arithmetic of step()/jac() keeps the operation order of the Python node
+// files (no FMA contraction: the translation unit is built with
+// -ffp-contract=off); only sin/cos/tan come from the device math library.
+//
+// Reference formulas:
+//   LAT      cilqr/lat_bicycle_node.py:32-91
+//   KIN      cilqr/full_bicycle_kinematic_node.py:31-105
+//   DYN      cilqr/full_bicycle_dynamic_node.py:32-108
+//   DYN_MID  cilqr/fast_bicycle_node.py:27-139
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/alilqr.h"
+
+namespace alilqr {
+
+constexpr double kPi = 3.141592653589793;
+constexpr double kTwoPi = 6.283185307179586;
+
+// (a + pi) % (2 pi) - pi with Python floor-mod semantics
+// (cilqr/lat_bicycle_node.py:23-25).  For a in [-pi, pi) the modulo is the
+// identity, which is the case on every call but the first on a raw start state.
+__device__ __forceinline__ double wrap_py(double a) {
+  double t = a + kPi;
+  if (t >= 0.0 && t < kTwoPi) return t - kPi;
+  double r = fmod(t, kTwoPi);
+  if (r != 0.0) {
+    if (r < 0.0) r += kTwoPi;
+  } else {
+    r = 0.0;
+  }
+  return r - kPi;
+}
+
+struct ModelConst {
+  double L, dt, v, k;
+};
+
+// ---------------------------------------------------------------------------
+// Structural description shared by the Riccati code.
+//   A = I + S : S(i,j) != 0 only where a_slot(i,j) >= 0 or a_const(i,j)
+//   B         : b_slot / b_const likewise
+// ---------------------------------------------------------------------------
+template <int MODEL>
+struct Model;
+
+// ---- 4 states / 1 control ---------------------------------------------------
+struct Lat4Base {
+  static constexpr int N = 4, M = 1;
+  static constexpr int NA = 5, NB = 1;
+  // compact A order: (0,2) (0,3) (1,2) (1,3) (2,3)
+  __host__ __device__ static constexpr int a_slot(int i, int j) {
+    return (i == 0 && j == 2) ? 0 : (i == 0 && j == 3) ? 1 : (i == 1 && j == 2) ? 2 : (i == 1 && j == 3) ? 3
+         : (i == 2 && j == 3) ? 4 : -1;
+  }
+  __host__ __device__ static constexpr bool a_is_dt(int, int) { return false; }
+  // compact B order: (2,0); (3,0) is the constant dt
+  __host__ __device__ static constexpr int b_slot(int i, int j) { return (i == 2 && j == 0) ? 0 : -1; }
+  __host__ __device__ static constexpr int b_const(int i, int j) { return (i == 3 && j == 0) ? 1 : 0; }  // 1: dt
+};
+
+template <>
+struct Model<ALILQR_MODEL_LAT> : Lat4Base {
+  __device__ static void step(const ModelConst& mc, const double* x, const double* u, double* xn) {
+    const double v = mc.v, dt = mc.dt, L = mc.L;
+    double th = wrap_py(x[2]), de = wrap_py(x[3]);
+    double s1, c1;
+    sincos(th, &s1, &c1);
+    double k1[4] = {v * c1, v * s1, v * tan(de) / L, u[0]};
+    double hdt = 0.5 * dt;
+    double mid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mid[i] = x[i] + hdt * k1[i];
+    double thm = wrap_py(mid[2]), dem = wrap_py(mid[3]);
+    double s2, c2;
+    sincos(thm, &s2, &c2);
+    double k2[4] = {v * c2, v * s2, v * tan(dem) / L, u[0]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xn[i] = x[i] + dt * k2[i];
+    xn[2] = wrap_py(xn[2]);
+    xn[3] = wrap_py(xn[3]);
+  }
+  __device__ static void jac(const ModelConst& mc, const double* x, const double* uc, double* a, double* b) {
+    const double v = mc.v, dt = mc.dt, L = mc.L;
+    double th = wrap_py(x[2]), de = wrap_py(x[3]);
+    double u = uc[0];
+    double td = tan(de);
+    double tm = th + 0.5 * dt * v * td / L;
+    double tu = tan(de + 0.5 * dt * u);
+    double sm, cm;
+    sincos(tm, &sm, &cm);
+    double dt2 = dt * dt, v2 = v * v;
+    a[0] = -dt * v * sm;
+    a[1] = -0.5 * dt2 * v2 * (td * td + 1) * sm / L;
+    a[2] = dt * v * cm;
+    a[3] = 0.5 * dt2 * v2 * (td * td + 1) * cm / L;
+    a[4] = dt * v * (tu * tu + 1) / L;
+    b[0] = 0.5 * dt2 * v * (tu * tu + 1) / L;
+  }
+};
+
+// ---- 6 states / 2 controls --------------------------------------------------
+struct Full6Base {
+  static constexpr int N = 6, M = 2;
+  static constexpr int NA = 11, NB = 1;
+  // compact A order: row 0 cols 2..5, row 1 cols 2..5, row 2 cols 3..5 ; (4,5) is the constant dt
+  __host__ __device__ static constexpr int a_slot(int i, int j) {
+    return (i == 0 && j >= 2) ? (j - 2) : (i == 1 && j >= 2) ? (4 + j - 2) : (i == 2 && j >= 3) ? (8 + j - 3) : -1;
+  }
+  __host__ __device__ static constexpr bool a_is_dt(int i, int j) { return i == 4 && j == 5; }
+  // compact B: (2,0) ; constants (3,0)=dt (4,1)=dt^2/2 (5,1)=dt
+  __host__ __device__ static constexpr int b_slot(int i, int j) { return (i == 2 && j == 0) ? 0 : -1; }
+  __host__ __device__ static constexpr int b_const(int i, int j) {
+    return (i == 3 && j == 0) ? 1 : (i == 4 && j == 1) ? 2 : (i == 5 && j == 1) ? 1 : 0;  // 1: dt, 2: dt^2/2
+  }
+};
+
+template <int MODEL>
+struct Full6 : Full6Base {
+  __device__ static void cont(const ModelConst& mc, const double* s, const double* u, double* out) {
+    double th = wrap_py(s[2]), de = wrap_py(s[3]);
+    double v = s[4], acc = s[5];
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    out[0] = v * cs;
+    out[1] = v * sn;
+    if (MODEL == ALILQR_MODEL_KIN)
+      out[2] = v * tan(de) / mc.L;
+    else
+      out[2] = v * tan(de) / (mc.L * (1 + mc.k * (v * v)));
+    out[3] = u[0];
+    out[4] = acc;
+    out[5] = u[1];
+  }
+  __device__ static void step(const ModelConst& mc, const double* x, const double* u, double* xn) {
+    double k1[6], k2[6], mid[6];
+    cont(mc, x, u, k1);
+    double hdt = 0.5 * mc.dt;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) mid[i] = x[i] + hdt * k1[i];
+    cont(mc, mid, u, k2);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xn[i] = x[i] + mc.dt * k2[i];
+    xn[2] = wrap_py(xn[2]);
+    xn[3] = wrap_py(xn[3]);
+  }
+  __device__ static void jac(const ModelConst& mc, const double* x, const double* uc, double* a, double* b) {
+    const double dt = mc.dt, L = mc.L, k = mc.k;
+    double theta = wrap_py(x[2]), delta = wrap_py(x[3]);
+    double v = x[4], acc = x[5], u1 = uc[0];
+    double dt2 = dt * dt;
+    double tan_delta = tan(delta);
+    double tan_u1 = tan(delta + 0.5 * dt * u1);
+    double vt = 0.5 * acc * dt + v;
+    if (MODEL == ALILQR_MODEL_KIN) {
+      double theta_mid = theta + 0.5 * dt * v * tan_delta / L;
+      double sn, c;
+      sincos(theta_mid, &sn, &c);
+      double tds = tan_delta * tan_delta, tus = tan_u1 * tan_u1;
+      double v_tu = v * (tus + 1);
+      a[0] = -dt * vt * sn;
+      a[1] = -0.5 * dt2 * v * vt * (tds + 1) * sn / L;
+      a[2] = dt * c - 0.5 * dt2 * vt * sn * tan_delta / L;
+      a[3] = 0.5 * dt2 * c;
+      a[4] = dt * vt * c;
+      a[5] = 0.5 * dt2 * v * vt * (tds + 1) * c / L;
+      a[6] = dt * sn + 0.5 * dt2 * vt * c * tan_delta / L;
+      a[7] = 0.5 * dt2 * sn;
+      a[8] = dt * v_tu / L;
+      a[9] = dt * tan_u1 / L;
+      a[10] = 0.5 * dt2 * tan_u1 / L;
+      b[0] = 0.5 * dt2 * v * (tus + 1) / L;
+    } else if (MODEL == ALILQR_MODEL_DYN) {
+      double sf = 1 + k * (v * v);
+      double theta_mid = theta + 0.5 * dt * v * tan_delta / (L * sf);
+      double sn, c;
+      sincos(theta_mid, &sn, &c);
+      double tds = tan_delta * tan_delta, tus = tan_u1 * tan_u1;
+      double v_tu = v * (tus + 1);
+      double g = -dt * k * (v * v) * tan_delta / (L * (sf * sf)) + 0.5 * dt * tan_delta / (L * sf);
+      a[0] = -dt * vt * sn;
+      a[1] = -0.5 * dt2 * v * vt * (tds + 1) * sn / (L * sf);
+      a[2] = dt * c - dt * vt * g * sn;
+      a[3] = 0.5 * dt2 * c;
+      a[4] = dt * vt * c;
+      a[5] = 0.5 * dt2 * v * vt * (tds + 1) * c / (L * sf);
+      a[6] = dt * sn + dt * vt * g * c;
+      a[7] = 0.5 * dt2 * sn;
+      a[8] = dt * v_tu / (L * sf);
+      a[9] = dt * tan_u1 / (L * sf) - dt * k * vt * (acc * dt + 2 * v) * tan_u1 / (L * (sf * sf));
+      a[10] = 0.5 * dt2 * tan_u1 / (L * sf) - 0.5 * dt2 * k * (vt * vt) * tan_u1 / (L * (sf * sf));
+      b[0] = 0.5 * dt2 * v_tu / (L * sf);
+    } else {  // DYN_MID
+      double k_v_sq = k * (v * v);
+      double k_vm_sq = k * (vt * vt);
+      double denom = L * (k_v_sq + 1);
+      double denom_mid = L * (k_vm_sq + 1);
+      double theta_mid = theta + 0.5 * dt * v * tan_delta / denom;
+      double sn, c;
+      sincos(theta_mid, &sn, &c);
+      double g = -dt * k_v_sq * tan_delta / (denom * denom) + 0.5 * dt * tan_delta / denom;
+      double tms = tan_u1 * tan_u1;
+      a[0] = -dt * vt * sn;
+      a[1] = -0.5 * dt2 * v * vt * (tan_delta * tan_delta + 1) * sn / denom;
+      a[2] = -dt * vt * g * sn + dt * c;
+      a[3] = 0.5 * dt2 * c;
+      a[4] = dt * vt * c;
+      a[5] = 0.5 * dt2 * v * vt * (tan_delta * tan_delta + 1) * c / denom;
+      a[6] = dt * vt * g * c + dt * sn;
+      a[7] = 0.5 * dt2 * sn;
+      a[8] = dt * vt * (tms + 1) / denom_mid;
+      a[9] = -dt * k_vm_sq * (1.0 * acc * dt + 2 * v) * tan_u1 / (denom_mid * denom_mid) + dt * tan_u1 / denom_mid;
+      a[10] = -dt2 * k_vm_sq * tan_u1 / (denom_mid * denom_mid) + 0.5 * dt2 * tan_u1 / denom_mid;
+      b[0] = 0.5 * dt2 * vt * (tms + 1) / denom_mid;
+    }
+  }
+};
+
+template <> struct Model<ALILQR_MODEL_KIN> : Full6<ALILQR_MODEL_KIN> {};
+template <> struct Model<ALILQR_MODEL_DYN> : Full6<ALILQR_MODEL_DYN> {};
+template <> struct Model<ALILQR_MODEL_DYN_MID> : Full6<ALILQR_MODEL_DYN_MID> {};
+
+}  // namespace alilqr

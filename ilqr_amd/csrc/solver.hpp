@@ -1,0 +1,936 @@
+// solver.hpp — the batched AL-iLQR solve kernel for gfx950.
+//
+// Mapping.  One problem is solved by a *lane group* of G lanes (G = 1..64, a
+// power of two, all inside one 64-lane wavefront).  A group is persistent: it
+// pulls problem indices from a global counter until the batch is drained, so
+// the device workspace is sized by the number of resident groups, not by the
+// batch.  Inside one inner iLQR iteration the G lanes are used three ways:
+//
+//   P1  linearise/quadratise   parallel in time: lane g takes nodes t = g, g+G, ...
+//   P2  backward Riccati       sequential in t; every lane of the group carries
+//                              the same (Vx, Vxx) in registers, lane 0 stores K, k
+//   P3  forward roll-outs      parallel over line-search trials: lane g rolls out
+//                              trial r*G+g+1 of round r; the first (largest
+//                              step) accepted trial wins, as in the sequential
+//                              reference
+//
+// All groups of a wave run the same flat loop (one inner iteration per trip),
+// so groups that are in different outer iterations, or on different problems,
+// still execute the heavy phases together.
+//
+// Data layout in HBM (fp64).  Workspace arrays are "element-major, group-minor"
+//   kk   [H*(M*N+M)]   [NG]      feedback K_t and feed-forward k_t
+//   lin  [(H+1)*E]     [NG]      per-node f_x, f_u (variable entries), l_x, l_u, l_xx, l_uu
+//   lam  [(H+1)*C]     [NG]      multipliers
+//   trj  [2][T]        [NG*G]    candidate trajectories, one slot per lane and parity
+// so a wave access to one element is one contiguous run of doubles.  The
+// current trajectory of a problem is the pair (slot lane, parity) of the last
+// accepted roll-out; nothing is copied on acceptance.
+//
+// Reference control flow restated here: cilqr/ilqr.py:11-192 (LEGACY, including
+// the array aliasing of forward() after its first rejected step, :137-138) and
+// cilqr/fast_ilqr.py:10-176 (FAST).
+#pragma once
+#include "models.hpp"
+
+namespace alilqr {
+
+struct KArgs {
+  int B, NG, H, C, goal_batch, table_nodes;
+  ModelConst mc;
+  alilqr_params prm;
+  const double *x0, *goals, *Q, *R, *cons;
+  double *x_out, *u_out, *node_x, *node_u, *x_init, *u_init, *cost, *viol, *lam, *mu;
+  int32_t* status;
+  double *trj, *kk, *lin, *lamw;
+  unsigned int* counter;
+};
+
+// ---- lane-group primitives ---------------------------------------------------
+template <int G>
+__device__ __forceinline__ double gbcast(double v, int src) {
+  if (G == 1) return v;
+  return __shfl(v, src, G);
+}
+template <int G>
+__device__ __forceinline__ int gbcast_i(int v, int src) {
+  if (G == 1) return v;
+  return __shfl(v, src, G);
+}
+// index of the first lane of the group whose predicate holds, or -1
+template <int G>
+__device__ __forceinline__ int gfirst(bool pred, int lane) {
+  if (G == 1) return pred ? 0 : -1;
+  unsigned long long b = __ballot(pred);
+  if (G < 64) {
+    int base = lane & ~(G - 1);
+    b = (b >> base) & ((1ull << G) - 1ull);
+  }
+  return b ? (__ffsll((long long)b) - 1) : -1;
+}
+
+// ---- per-node record in `lin` ---------------------------------------------------
+template <class MD>
+struct LinLayout {
+  static constexpr int N = MD::N, M = MD::M;
+  static constexpr int oA = 0, oB = oA + MD::NA, oLx = oB + MD::NB, oLu = oLx + N, oLxx = oLu + M,
+                       oLuu = oLxx + N * N, E = oLuu + M * M;
+};
+
+template <class MD>
+__host__ __device__ constexpr bool s_nz(int i, int j) { return MD::a_slot(i, j) >= 0 || MD::a_is_dt(i, j); }
+template <class MD>
+__host__ __device__ constexpr bool b_nz(int i, int j) { return MD::b_slot(i, j) >= 0 || MD::b_const(i, j) != 0; }
+
+// expand the compact Jacobian into register matrices S (= A - I) and B
+template <class MD>
+__device__ __forceinline__ void expand_jac(const ModelConst& mc, const double* a, const double* b,
+                                           double (&S)[MD::N][MD::N], double (&Bm)[MD::N][MD::M]) {
+  constexpr int N = MD::N, M = MD::M;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      if (MD::a_slot(i, j) >= 0) S[i][j] = a[MD::a_slot(i, j)];
+      else if (MD::a_is_dt(i, j)) S[i][j] = mc.dt;
+      else S[i][j] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      if (MD::b_slot(i, j) >= 0) Bm[i][j] = b[MD::b_slot(i, j)];
+      else if (MD::b_const(i, j) == 1) Bm[i][j] = mc.dt;
+      else if (MD::b_const(i, j) == 2) Bm[i][j] = 0.5 * (mc.dt * mc.dt);
+      else Bm[i][j] = 0.0;
+    }
+  }
+}
+
+// W = V (I + S)
+template <class MD>
+__device__ __forceinline__ void mul_VA(const double (&V)[MD::N][MD::N], const double (&S)[MD::N][MD::N],
+                                       double (&W)[MD::N][MD::N]) {
+  constexpr int N = MD::N;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double acc = V[i][j];
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+        if (s_nz<MD>(k, j)) acc = fma(V[i][k], S[k][j], acc);
+      W[i][j] = acc;
+    }
+}
+// T = V B
+template <class MD>
+__device__ __forceinline__ void mul_VB(const double (&V)[MD::N][MD::N], const double (&Bm)[MD::N][MD::M],
+                                       double (&T)[MD::N][MD::M]) {
+  constexpr int N = MD::N, M = MD::M;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int b = 0; b < M; ++b) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+        if (b_nz<MD>(k, b)) acc = fma(V[i][k], Bm[k][b], acc);
+      T[i][b] = acc;
+    }
+}
+// inverse of an M x M matrix (M = 1 or 2), closed form
+template <int M>
+__device__ __forceinline__ void inv_small(const double (&Qm)[M][M], double (&Qi)[M][M]) {
+  if (M == 1) {
+    Qi[0][0] = 1.0 / Qm[0][0];
+  } else {
+    double det = Qm[0][0] * Qm[1][1] - Qm[0][1] * Qm[1][0];
+    double r = 1.0 / det;
+    Qi[0][0] = Qm[1][1] * r;
+    Qi[0][1] = -Qm[0][1] * r;
+    Qi[1][0] = -Qm[1][0] * r;
+    Qi[1][1] = Qm[0][0] * r;
+  }
+}
+
+// One step of the backward recursion (cilqr/ilqr.py:85-98).
+template <class MD>
+__device__ __forceinline__ void riccati_step(const double (&S)[MD::N][MD::N], const double (&Bm)[MD::N][MD::M],
+                                             const double* lx, const double* lu, const double* lxx, const double* luu,
+                                             size_t stride, double reg,
+                                             double (&Vx)[MD::N], double (&Vxx)[MD::N][MD::N],
+                                             double (&K)[MD::M][MD::N], double (&kf)[MD::M]) {
+  constexpr int N = MD::N, M = MD::M;
+  double Qx[N], Qu[M];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double acc = lx[i * stride] + Vx[i];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (s_nz<MD>(k, i)) acc = fma(S[k][i], Vx[k], acc);
+    Qx[i] = acc;
+  }
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+    double acc = lu[a * stride];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (b_nz<MD>(k, a)) acc = fma(Bm[k][a], Vx[k], acc);
+    Qu[a] = acc;
+  }
+  double W[N][N], T[N][M];
+  mul_VA<MD>(Vxx, S, W);
+  mul_VB<MD>(Vxx, Bm, T);
+  double Qux[M][N], Quu[M][M], Qr[M][M], Qi[M][M];
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+        if (b_nz<MD>(k, a)) acc = fma(Bm[k][a], W[k][j], acc);
+      Qux[a][j] = acc;
+    }
+#pragma unroll
+    for (int b = 0; b < M; ++b) {
+      double acc = luu[(a * M + b) * stride];
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+        if (b_nz<MD>(k, a)) acc = fma(Bm[k][a], T[k][b], acc);
+      Quu[a][b] = acc;
+      Qr[a][b] = acc + ((a == b) ? reg : 0.0);
+    }
+  }
+  inv_small<M>(Qr, Qi);
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double acc = 0.0;
+#pragma unroll
+      for (int b = 0; b < M; ++b) acc = fma(-Qi[a][b], Qux[b][j], acc);
+      K[a][j] = acc;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int b = 0; b < M; ++b) acc = fma(-Qi[a][b], Qu[b], acc);
+    kf[a] = acc;
+  }
+  // Quu k and Quu K
+  double Qk[M], QK[M][N];
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+    double acc = 0.0;
+#pragma unroll
+    for (int b = 0; b < M; ++b) acc = fma(Quu[a][b], kf[b], acc);
+    Qk[a] = acc;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double acc2 = 0.0;
+#pragma unroll
+      for (int b = 0; b < M; ++b) acc2 = fma(Quu[a][b], K[b][j], acc2);
+      QK[a][j] = acc2;
+    }
+  }
+  // Qxx = lxx + A'W, then Vxx = Qxx + K'QuuK + K'Qux + Qux'K ; Vx likewise
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double vx = Qx[i];
+#pragma unroll
+    for (int a = 0; a < M; ++a) vx = fma(K[a][i], Qk[a], vx);
+#pragma unroll
+    for (int a = 0; a < M; ++a) vx = fma(K[a][i], Qu[a], vx);
+#pragma unroll
+    for (int a = 0; a < M; ++a) vx = fma(Qux[a][i], kf[a], vx);
+    Vx[i] = vx;
+  }
+  double Vn[N][N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double acc = lxx[(i * N + j) * stride] + W[i][j];
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+        if (s_nz<MD>(k, i)) acc = fma(S[k][i], W[k][j], acc);
+#pragma unroll
+      for (int a = 0; a < M; ++a) acc = fma(K[a][i], QK[a][j], acc);
+#pragma unroll
+      for (int a = 0; a < M; ++a) acc = fma(K[a][i], Qux[a][j], acc);
+#pragma unroll
+      for (int a = 0; a < M; ++a) acc = fma(Qux[a][i], K[a][j], acc);
+      Vn[i][j] = acc;
+    }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) Vxx[i][j] = Vn[i][j];
+}
+
+// ---------------------------------------------------------------------------
+// Node cost / quadratisation / multiplier algebra per solver generation.
+// `lam` points at this node's first multiplier in the workspace (stride NG).
+// ---------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ double quad_form(const double* e, const double* Q) {  // e' Q e, reference order
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) t += e[i] * Q[i * N + j];
+    s += t * e[j];
+  }
+  return s;
+}
+
+template <int MODEL, int MODE>
+struct NodeOps;
+
+// LEGACY: box bounds folded into the node with the I_mu mask
+// (cilqr/lat_bicycle_node.py:93-180; dyn variant full_bicycle_dynamic_node.py:110-197)
+template <int MODEL>
+struct NodeOps<MODEL, ALILQR_MODE_LEGACY> {
+  using MD = Model<MODEL>;
+  static constexpr int N = MD::N, M = MD::M, C = 2 * (N + M);
+
+  // constraint i of (x,u): [x - smax ; smin - x ; u - cmax ; cmin - u]
+  __device__ static __forceinline__ double cval(const double* box, const double* x, const double* u, int i) {
+    const double *smin = box, *smax = box + N, *cmin = box + 2 * N, *cmax = box + 2 * N + M;
+    if (i < N) return x[i] - smax[i];
+    if (i < 2 * N) return smin[i - N] - x[i - N];
+    if (i < 2 * N + M) return u[i - 2 * N] - cmax[i - 2 * N];
+    return cmin[i - 2 * N - M] - u[i - 2 * N - M];
+  }
+  __device__ static double cost(const KArgs& a, const double* Q, const double* R, const double* box,
+                                const double* x, const double* u, const double* g,
+                                const double* lam, size_t ls, double mu) {
+    double e[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = x[i] - g[i];
+    double sc = quad_form<N>(e, Q);
+    double cc = quad_form<M>(u, R);
+    double lc = 0.0, qc = 0.0;
+    const double half = (MODEL == ALILQR_MODEL_DYN) ? 0.5 : 0.5 * mu;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+      double c = cval(box, x, u, i);
+      double l = lam[i * ls];
+      double im = (l == 0.0 && c <= 0.0) ? 0.0 : mu;
+      lc += l * c;
+      qc += ((half * c) * im) * c;
+    }
+    (void)a;
+    return sc + cc + (lc + qc);
+  }
+  // l_x, l_u, l_xx, l_uu written straight into the node's `lin` record
+  __device__ static void quadratize(const KArgs& a, const double* Q, const double* R, const double* box,
+                                    const double* x, const double* u, const double* g,
+                                    const double* lam, size_t ls, double mu,
+                                    double* rec, size_t rs) {
+    using LL = LinLayout<MD>;
+    double e[N], w[C], im[C];
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = x[i] - g[i];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+      double c = cval(box, x, u, i);
+      double l = lam[i * ls];
+      im[i] = (l == 0.0 && c <= 0.0) ? 0.0 : mu;
+      w[i] = l + im[i] * c;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) s += (2 * Q[i * N + j]) * e[j];
+      rec[(LL::oLx + i) * rs] = s + (w[i] - w[N + i]);
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        rec[(LL::oLxx + i * N + j) * rs] = (i == j) ? (2 * Q[i * N + j] + (im[i] + im[N + i])) : 2 * Q[i * N + j];
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < M; ++j) s += (2 * R[i * M + j]) * u[j];
+      rec[(LL::oLu + i) * rs] = s + (w[2 * N + i] - w[2 * N + M + i]);
+#pragma unroll
+      for (int j = 0; j < M; ++j)
+        rec[(LL::oLuu + i * M + j) * rs] =
+            (i == j) ? (2 * R[i * M + j] + (im[2 * N + i] + im[2 * N + M + i])) : 2 * R[i * M + j];
+    }
+    (void)a;
+  }
+  // per-node term of the violation measure: || max(-lam/mu, c) ||_2  (cilqr/ilqr.py:186-192)
+  __device__ static double violation(const KArgs& a, const double* box, const double* x, const double* u,
+                                     const double* lam, size_t ls, double mu) {
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+      double c = cval(box, x, u, i);
+      double one = fmax(-lam[i * ls] / mu, c);
+      ss += one * one;
+    }
+    (void)a;
+    return sqrt(ss);
+  }
+  __device__ static double combine_violation(double acc, double node) { return acc + node; }
+  __device__ static double violation_init() { return 0.0; }
+  // lam <- max(0, lam + mu c)   (cilqr/lat_bicycle_node.py:162-165)
+  __device__ static void update_lambda(const KArgs& a, const double* box, const double* x, const double* u,
+                                       double* lam, size_t ls, double mu) {
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+      double c = cval(box, x, u, i);
+      lam[i * ls] = fmax(0.0, lam[i * ls] + mu * c);
+    }
+    (void)a;
+  }
+};
+
+// FAST: projection-form AL over a linear table c(x,u) = A x + B u + C <= 0
+// (cilqr/constraints.py:47-119, linear_constraints.py:13-29, fast_bicycle_node.py:183-212)
+template <int MODEL>
+struct NodeOps<MODEL, ALILQR_MODE_FAST> {
+  using MD = Model<MODEL>;
+  static constexpr int N = MD::N, M = MD::M;
+
+  __device__ static __forceinline__ double cval(const KArgs& a, const double* tab, const double* x, const double* u, int i) {
+    const double *A = tab, *Bm = tab + a.C * N, *Cv = tab + a.C * (N + M);
+    double ax = 0.0, bu = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) ax += A[i * N + j] * x[j];
+#pragma unroll
+    for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
+    return (ax + bu) + Cv[i];
+  }
+  __device__ static double cost(const KArgs& a, const double* Q, const double* R, const double* tab,
+                                const double* x, const double* u, const double* g,
+                                const double* lam, size_t ls, double mu) {
+    double e[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = x[i] - g[i];
+    double sc = quad_form<N>(e, Q);
+    double cc = quad_form<M>(u, R);
+    double pp = 0.0, ll = 0.0;
+    for (int i = 0; i < a.C; ++i) {
+      double l = lam[i * ls];
+      double f = l - mu * cval(a, tab, x, u, i);
+      double lp = fmin(f, 0.0);
+      pp += lp * lp;
+      ll += l * l;
+    }
+    return sc + cc + 0.5 / mu * (pp - ll);
+  }
+  __device__ static void quadratize(const KArgs& a, const double* Q, const double* R, const double* tab,
+                                    const double* x, const double* u, const double* g,
+                                    const double* lam, size_t ls, double mu,
+                                    double* rec, size_t rs) {
+    using LL = LinLayout<MD>;
+    const double *A = tab, *Bm = tab + a.C * N;
+    double e[N], jx[N], ju[M], hx[N][N], hu[M][M];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { e[i] = x[i] - g[i]; jx[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < M; ++i) ju[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < N; ++j) hx[i][j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = 0; j < M; ++j) hu[i][j] = 0.0;
+    for (int i = 0; i < a.C; ++i) {
+      double f = lam[i * ls] - mu * cval(a, tab, x, u, i);
+      double lp = fmin(f, 0.0);
+      double pj = (f > 0.0) ? 0.0 : 1.0;
+      double pa[N], pb[M];
+#pragma unroll
+      for (int j = 0; j < N; ++j) { pa[j] = pj * A[i * N + j]; jx[j] += pa[j] * lp; }
+#pragma unroll
+      for (int j = 0; j < M; ++j) { pb[j] = pj * Bm[i * M + j]; ju[j] += pb[j] * lp; }
+#pragma unroll
+      for (int p = 0; p < N; ++p)
+#pragma unroll
+        for (int q = 0; q < N; ++q) hx[p][q] += pa[p] * pa[q];
+#pragma unroll
+      for (int p = 0; p < M; ++p)
+#pragma unroll
+        for (int q = 0; q < M; ++q) hu[p][q] += pb[p] * pb[q];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) s += (2 * Q[i * N + j]) * e[j];
+      rec[(LL::oLx + i) * rs] = s + (-jx[i]);
+#pragma unroll
+      for (int j = 0; j < N; ++j) rec[(LL::oLxx + i * N + j) * rs] = 2 * Q[i * N + j] + (mu * hx[i][j] - 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < M; ++j) s += (2 * R[i * M + j]) * u[j];
+      rec[(LL::oLu + i) * rs] = s + (-ju[i]);
+#pragma unroll
+      for (int j = 0; j < M; ++j) rec[(LL::oLuu + i * M + j) * rs] = 2 * R[i * M + j] + (mu * hu[i][j] - 0.0);
+    }
+  }
+  // per-node || c - min(c,0) ||_inf  (cilqr/constraints.py:115-119)
+  __device__ static double violation(const KArgs& a, const double* tab, const double* x, const double* u,
+                                     const double* lam, size_t ls, double mu) {
+    double v = 0.0;
+    for (int i = 0; i < a.C; ++i) {
+      double c = cval(a, tab, x, u, i);
+      double dc = fabs(c - fmin(c, 0.0));
+      v = (dc > v || dc != dc) ? dc : v;
+    }
+    (void)lam; (void)ls; (void)mu;
+    return v;
+  }
+  // np.maximum over nodes, seeded with -1 (cilqr/fast_ilqr.py:171-176); NaN propagates
+  __device__ static double combine_violation(double acc, double node) { return (node > acc || node != node) ? node : acc; }
+  __device__ static double violation_init() { return -1.0; }
+  // lam <- min(lam - mu c, 0)  (cilqr/constraints.py:106-110; c is the value cached by max_violation at the same point)
+  __device__ static void update_lambda(const KArgs& a, const double* tab, const double* x, const double* u,
+                                       double* lam, size_t ls, double mu) {
+    for (int i = 0; i < a.C; ++i) {
+      double c = cval(a, tab, x, u, i);
+      lam[i * ls] = fmin(lam[i * ls] - mu * c, 0.0);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------
+template <int MODEL, int MODE, int G>
+__global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
+  using MD = Model<MODEL>;
+  using OPS = NodeOps<MODEL, MODE>;
+  using LL = LinLayout<MD>;
+  constexpr int N = MD::N, M = MD::M;
+  constexpr bool LEGACY = (MODE == ALILQR_MODE_LEGACY);
+
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (G - 1);                       // lane inside the group
+  const size_t lg = (size_t)blockIdx.x * 64 + lane;    // global lane
+  const size_t gid = lg / G;                           // global group
+  if (gid >= (size_t)a.NG) return;                     // whole groups only: NG*G is a multiple of 64 by construction
+
+  const int H = a.H, C = a.C;
+  const size_t NG = (size_t)a.NG, LT = NG * G;
+  const int XS = (H + 1) * N, US = H * M, T = XS + US;
+  const ModelConst mc = a.mc;
+  const int KS = M * N + M;   // doubles of (K_t, k_t)
+
+  double* const trj = a.trj;
+  double* const kk = a.kk + gid;
+  double* const lin = a.lin + gid;
+  double* const lamw = a.lamw + gid;
+  const int cw = LEGACY ? (2 * N + 2 * M) : C * (N + M + 1);   // doubles per constraint table
+
+  // number of line-search trials the reference can make: alpha = 1, 1/2, ... while alpha > alpha_min
+  int ntrials = 0;
+  for (double al = 1.0; al > a.prm.alpha_min && ntrials < 64; al = al / 2.0) ++ntrials;
+
+  // ---- per-group state (identical in every lane of a group) ----
+  int p = -1;                 // problem being solved, -1: none
+  bool drained = false;       // the batch counter ran out
+  int cur_lane = 0, cur_par = 0;
+  double mu = 1.0, old_cost = 0.0, viol = 0.0;
+  int outer = 0, inner = 0, n_inner = 0, n_trials = 0;
+  bool outer_start = false;
+  const double* goals = a.goals;
+
+  auto trj_at = [&](int par, int off, size_t slot_lane) -> double* {
+    return trj + ((size_t)par * T + off) * LT + slot_lane;
+  };
+  auto tabQ = [&](int t) { return a.Q + (size_t)((a.table_nodes > 1) ? t : 0) * N * N; };
+  auto tabR = [&](int t) { return a.R + (size_t)((a.table_nodes > 1) ? t : 0) * M * M; };
+  auto tabC = [&](int t) { return a.cons + (size_t)((a.table_nodes > 1) ? t : 0) * cw; };
+
+  // total cost of the current trajectory: node costs in parallel, summed in node order (ilqr.py:52-56)
+  auto total_cost = [&]() -> double {
+    const size_t cs = gid * G + cur_lane;
+    double total = 0.0;
+    for (int t0 = 0; t0 <= H; t0 += G) {
+      int t = t0 + gl;
+      double ct = 0.0;
+      if (t <= H) {
+        double x[N], u[M];
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = *trj_at(cur_par, t * N + i, cs);
+#pragma unroll
+        for (int j = 0; j < M; ++j) u[j] = (t < H) ? *trj_at(cur_par, XS + t * M + j, cs) : 0.0;
+        ct = OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, goals + (size_t)t * N, lamw + (size_t)t * C * NG, NG, mu);
+      }
+      for (int g = 0; g < G && t0 + g <= H; ++g) total += gbcast<G>(ct, g);
+    }
+    return total;
+  };
+
+  for (;;) {
+    // ================= problem switch: pull + initial guess =================
+    if (p < 0 && !drained) {
+      int np = 0;
+      if (gl == 0) np = (int)atomicAdd(a.counter, 1u);
+      np = gbcast_i<G>(np, 0);
+      if (np >= a.B) {
+        drained = true;
+      } else {
+        p = np;
+        goals = a.goals + ((a.goal_batch > 1) ? (size_t)p * XS : 0);
+        // ---- linearised-LQR initial guess (ilqr.py:11-50): every lane of the group
+        //      carries the same recursion; lane 0 stores.
+        double P[N][N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+          for (int j = 0; j < N; ++j) P[i][j] = (i == j) ? 1.0 : 0.0;
+        for (int t = H - 1; t >= 0; --t) {
+          double ac[MD::NA], bc[MD::NB], S[N][N], Bm[N][M], zu[M];
+#pragma unroll
+          for (int j = 0; j < M; ++j) zu[j] = 0.0;
+          double gt[N];
+#pragma unroll
+          for (int i = 0; i < N; ++i) gt[i] = goals[(size_t)t * N + i];
+          MD::jac(mc, gt, zu, ac, bc);
+          expand_jac<MD>(mc, ac, bc, S, Bm);
+          double W[N][N], Tm[N][M], Mx[M][M], Mi[M][M], BtPA[M][N], Kt[M][N];
+          mul_VA<MD>(P, S, W);
+          mul_VB<MD>(P, Bm, Tm);
+#pragma unroll
+          for (int r = 0; r < M; ++r) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+              double acc = 0.0;
+#pragma unroll
+              for (int k = 0; k < N; ++k)
+                if (b_nz<MD>(k, r)) acc = fma(Bm[k][r], W[k][j], acc);
+              BtPA[r][j] = acc;
+            }
+#pragma unroll
+            for (int b = 0; b < M; ++b) {
+              double acc = (r == b) ? a.prm.init_r : 0.0;
+#pragma unroll
+              for (int k = 0; k < N; ++k)
+                if (b_nz<MD>(k, r)) acc = fma(Bm[k][r], Tm[k][b], acc);
+              Mx[r][b] = acc;
+            }
+          }
+          inv_small<M>(Mx, Mi);
+#pragma unroll
+          for (int r = 0; r < M; ++r)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+              double acc = 0.0;
+#pragma unroll
+              for (int b = 0; b < M; ++b) acc = fma(Mi[r][b], BtPA[b][j], acc);
+              Kt[r][j] = acc;
+              if (gl == 0) kk[(size_t)(t * KS + r * N + j) * NG] = acc;
+            }
+          // P = I + A'(W - T K)
+          double D[N][N];
+#pragma unroll
+          for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+              double acc = W[i][j];
+#pragma unroll
+              for (int b = 0; b < M; ++b) acc = fma(-Tm[i][b], Kt[b][j], acc);
+              D[i][j] = acc;
+            }
+#pragma unroll
+          for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+              double acc = ((i == j) ? 1.0 : 0.0) + D[i][j];
+#pragma unroll
+              for (int k = 0; k < N; ++k)
+                if (s_nz<MD>(k, i)) acc = fma(S[k][i], D[k][j], acc);
+              P[i][j] = acc;
+            }
+        }
+        __threadfence_block();
+        // roll-out u = -K (x - goal) from the raw start state; trajectory goes to slot (lane 0, parity 0)
+        {
+          const size_t cs = gid * G;
+          double x[N];
+#pragma unroll
+          for (int i = 0; i < N; ++i) x[i] = a.x0[(size_t)p * N + i];
+          if (gl == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+              if (a.x_init) a.x_init[(size_t)p * XS + i] = x[i];
+              a.x_out[(size_t)p * XS + i] = x[i];
+              // node 0 keeps the wrapped start state from its first cost() call on (lat_bicycle_node.py:27-30,94)
+              *trj_at(0, i, cs) = (i == 2 || i == 3) ? wrap_py(x[i]) : x[i];
+            }
+          }
+          for (int t = 0; t < H; ++t) {
+            double u[M], xn[N];
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+              double acc = 0.0;
+#pragma unroll
+              for (int i = 0; i < N; ++i) acc += (-kk[(size_t)(t * KS + r * N + i) * NG]) * (x[i] - goals[(size_t)t * N + i]);
+              u[r] = acc;
+            }
+            MD::step(mc, x, u, xn);
+            if (gl == 0) {
+#pragma unroll
+              for (int r = 0; r < M; ++r) {
+                *trj_at(0, XS + t * M + r, cs) = u[r];
+                if (a.u_init) a.u_init[(size_t)p * US + t * M + r] = u[r];
+                a.u_out[(size_t)p * US + t * M + r] = u[r];
+              }
+#pragma unroll
+              for (int i = 0; i < N; ++i) {
+                *trj_at(0, (t + 1) * N + i, cs) = xn[i];
+                if (a.x_init) a.x_init[(size_t)p * XS + (t + 1) * N + i] = xn[i];
+                a.x_out[(size_t)p * XS + (t + 1) * N + i] = xn[i];
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) x[i] = xn[i];
+          }
+        }
+        for (int e = gl; e < (H + 1) * C; e += G) lamw[(size_t)e * NG] = 0.0;
+        mu = 1.0;
+        cur_lane = 0; cur_par = 0;
+        outer = 0; inner = 0; n_inner = 0; n_trials = 0;
+        outer_start = true;
+        __threadfence_block();
+      }
+    }
+    // every group of the wave idle and nothing left to pull: done
+    if (__ballot(p >= 0) == 0ull) break;
+
+    if (p >= 0) {
+      // ================= outer-iteration start: J under the current multipliers =================
+      if (outer_start) {
+        old_cost = total_cost();
+        outer_start = false;
+        inner = 0;
+      }
+      const size_t cs = gid * G + cur_lane;     // slot of the current trajectory
+      const int np_ = 1 - cur_par;              // parity the candidates are written to
+      const size_t myslot = gid * G + gl;
+
+      // ================= P1: linearise + quadratise, parallel in time =================
+      for (int t = gl; t <= H; t += G) {
+        double x[N], u[M];
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = *trj_at(cur_par, t * N + i, cs);
+#pragma unroll
+        for (int j = 0; j < M; ++j) u[j] = (t < H) ? *trj_at(cur_par, XS + t * M + j, cs) : 0.0;
+        double* rec = lin + (size_t)t * LL::E * NG;
+        if (t < H) {
+          double ac[MD::NA], bc[MD::NB];
+          MD::jac(mc, x, u, ac, bc);
+#pragma unroll
+          for (int i = 0; i < MD::NA; ++i) rec[(size_t)(LL::oA + i) * NG] = ac[i];
+#pragma unroll
+          for (int i = 0; i < MD::NB; ++i) rec[(size_t)(LL::oB + i) * NG] = bc[i];
+        }
+        OPS::quadratize(a, tabQ(t), tabR(t), tabC(t), x, u, goals + (size_t)t * N,
+                        lamw + (size_t)t * C * NG, NG, mu, rec, NG);
+      }
+      __threadfence_block();
+
+      // ================= P2: backward Riccati sweep =================
+      {
+        double Vx[N], Vxx[N][N];
+        const double* recH = lin + (size_t)H * LL::E * NG;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          Vx[i] = recH[(size_t)(LL::oLx + i) * NG];
+#pragma unroll
+          for (int j = 0; j < N; ++j) Vxx[i][j] = recH[(size_t)(LL::oLxx + i * N + j) * NG];
+        }
+        for (int t = H - 1; t >= 0; --t) {
+          const double* rec = lin + (size_t)t * LL::E * NG;
+          double ac[MD::NA], bc[MD::NB], S[N][N], Bm[N][M], K[M][N], kf[M];
+#pragma unroll
+          for (int i = 0; i < MD::NA; ++i) ac[i] = rec[(size_t)(LL::oA + i) * NG];
+#pragma unroll
+          for (int i = 0; i < MD::NB; ++i) bc[i] = rec[(size_t)(LL::oB + i) * NG];
+          expand_jac<MD>(mc, ac, bc, S, Bm);
+          riccati_step<MD>(S, Bm, rec + (size_t)LL::oLx * NG, rec + (size_t)LL::oLu * NG,
+                           rec + (size_t)LL::oLxx * NG, rec + (size_t)LL::oLuu * NG, NG, a.prm.quu_reg,
+                           Vx, Vxx, K, kf);
+          if (gl == 0) {
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+#pragma unroll
+              for (int j = 0; j < N; ++j) kk[(size_t)(t * KS + r * N + j) * NG] = K[r][j];
+              kk[(size_t)(t * KS + M * N + r) * NG] = kf[r];
+            }
+          }
+        }
+      }
+      __threadfence_block();
+
+      // ================= P3: roll-outs, one line-search trial per lane =================
+      double new_cost = old_cost;
+      int win_lane = -1;
+      int rounds = 0;
+      for (int r0 = 0; r0 < ntrials && win_lane < 0; r0 += G, ++rounds) {
+        const int j = r0 + gl + 1;              // trial number, 1-based
+        const bool valid = j <= ntrials;
+        // alpha_j = 2^-(j-1) (exact halvings, ilqr.py:136)
+        double alpha = 1.0;
+        for (int q = 1; q < j && q < 64; ++q) alpha = alpha / 2.0;
+        const bool closed = (!LEGACY) || (j == 1);    // LEGACY trials >= 2 run open loop on accumulated controls
+        // LEGACY open-loop trials: u_j = (...((base + a_s k) + a_{s+1} k)...) + a_j k
+        const bool from_cur = (r0 == 0) || (r0 == G && gl == 0);
+        const int jstart = (r0 == 0) ? 2 : (j - G + 1);
+        double J = 0.0;
+        double x[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          x[i] = *trj_at(cur_par, i, cs);
+          if (valid) *trj_at(np_, i, myslot) = x[i];
+        }
+        for (int t = 0; t < H; ++t) {
+          double xo[N], uo[M], u[M], kf[M];
+#pragma unroll
+          for (int i = 0; i < N; ++i) xo[i] = *trj_at(cur_par, t * N + i, cs);
+#pragma unroll
+          for (int r = 0; r < M; ++r) {
+            uo[r] = *trj_at(cur_par, XS + t * M + r, cs);
+            kf[r] = kk[(size_t)(t * KS + M * N + r) * NG];
+          }
+          if (closed) {
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+              double fb = 0.0;
+#pragma unroll
+              for (int i = 0; i < N; ++i) fb += kk[(size_t)(t * KS + r * N + i) * NG] * (x[i] - xo[i]);
+              u[r] = (uo[r] + alpha * kf[r]) + fb;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+              double base = from_cur ? uo[r] : *trj_at(np_, XS + t * M + r, myslot);
+              double al = 1.0;
+              for (int q = 1; q < jstart && q < 64; ++q) al = al / 2.0;   // alpha_{jstart}
+              for (int q = jstart; q <= j; ++q) { base = base + al * kf[r]; al = al / 2.0; }
+              u[r] = base;
+            }
+          }
+          if (valid) {
+            J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, goals + (size_t)t * N, lamw + (size_t)t * C * NG, NG, mu);
+            double xn[N];
+            MD::step(mc, x, u, xn);
+#pragma unroll
+            for (int r = 0; r < M; ++r) *trj_at(np_, XS + t * M + r, myslot) = u[r];
+#pragma unroll
+            for (int i = 0; i < N; ++i) { x[i] = xn[i]; *trj_at(np_, (t + 1) * N + i, myslot) = xn[i]; }
+          }
+        }
+        if (valid) {
+          double zu[M];
+#pragma unroll
+          for (int r = 0; r < M; ++r) zu[r] = 0.0;
+          J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, goals + (size_t)H * N, lamw + (size_t)H * C * NG, NG, mu);
+        }
+        const bool ok = valid && (J < old_cost);
+        int w = gfirst<G>(ok, lane);
+        int nv = ntrials - r0; if (nv > G) nv = G;      // trials evaluated this round
+        if (w >= 0) {
+          win_lane = w;
+          new_cost = gbcast<G>(J, w);
+          n_trials += w + 1;
+        } else {
+          n_trials += nv;
+          if (LEGACY && r0 + G >= ntrials) {
+            // every step rejected: the reference is left holding the last trial's arrays (ilqr.py:137-147)
+            win_lane = nv - 1;
+            new_cost = gbcast<G>(J, win_lane);
+          }
+        }
+      }
+      if (win_lane >= 0) { cur_lane = win_lane; cur_par = np_; }
+      __threadfence_block();
+
+      // ================= P4: inner / outer bookkeeping (ilqr.py:158-174) =================
+      ++n_inner; ++inner;
+      const bool brk = fabs(new_cost - old_cost) < a.prm.inner_tol;
+      if (!brk) {
+        // x, u = new_x, new_u : the pair optimize() will return
+        const size_t ns = gid * G + cur_lane;
+        for (int e = gl; e < XS; e += G) a.x_out[(size_t)p * XS + e] = *trj_at(cur_par, e, ns);
+        for (int e = gl; e < US; e += G) a.u_out[(size_t)p * US + e] = *trj_at(cur_par, XS + e, ns);
+        old_cost = new_cost;
+      }
+      bool finished = false;
+      unsigned flags = 0;
+      if (brk || inner >= a.prm.max_inner) {
+        const size_t ns = gid * G + cur_lane;
+        // constraint violation of the node trajectory, nodes in parallel, combined in node order
+        double vtot = OPS::violation_init();
+        for (int t0 = 0; t0 <= H; t0 += G) {
+          int t = t0 + gl;
+          double vt = 0.0;
+          if (t <= H) {
+            double x[N], u[M];
+#pragma unroll
+            for (int i = 0; i < N; ++i) x[i] = *trj_at(cur_par, t * N + i, ns);
+#pragma unroll
+            for (int j = 0; j < M; ++j) u[j] = (t < H) ? *trj_at(cur_par, XS + t * M + j, ns) : 0.0;
+            vt = OPS::violation(a, tabC(t), x, u, lamw + (size_t)t * C * NG, NG, mu);
+          }
+          for (int g = 0; g < G && t0 + g <= H; ++g) vtot = OPS::combine_violation(vtot, gbcast<G>(vt, g));
+        }
+        viol = vtot;
+        ++outer;
+        if (viol < a.prm.viol_stop) {
+          finished = true; flags = ALILQR_FLAG_VIOL_OK;
+        } else {
+          if (viol >= a.prm.viol_stop && viol < a.prm.viol_lambda) {
+            for (int t = gl; t <= H; t += G) {
+              double x[N], u[M];
+#pragma unroll
+              for (int i = 0; i < N; ++i) x[i] = *trj_at(cur_par, t * N + i, ns);
+#pragma unroll
+              for (int j = 0; j < M; ++j) u[j] = (t < H) ? *trj_at(cur_par, XS + t * M + j, ns) : 0.0;
+              OPS::update_lambda(a, tabC(t), x, u, lamw + (size_t)t * C * NG, NG, mu);
+            }
+            __threadfence_block();
+          } else {
+            mu = mu * a.prm.mu_gain;
+          }
+          if (outer >= a.prm.max_outer) { finished = true; flags = ALILQR_FLAG_OUTER_CAP; }
+          else outer_start = true;
+        }
+      }
+      if (finished) {
+        const size_t ns = gid * G + cur_lane;
+        double fc = total_cost();
+        if (a.node_x) for (int e = gl; e < XS; e += G) a.node_x[(size_t)p * XS + e] = *trj_at(cur_par, e, ns);
+        if (a.node_u) for (int e = gl; e < US; e += G) a.node_u[(size_t)p * US + e] = *trj_at(cur_par, XS + e, ns);
+        if (a.lam) for (int e = gl; e < (H + 1) * C; e += G) a.lam[(size_t)p * (H + 1) * C + e] = lamw[(size_t)e * NG];
+        if (gl == 0) {
+          a.cost[p] = fc;
+          if (a.viol) a.viol[p] = viol;
+          if (a.mu) a.mu[p] = mu;
+          if (a.status) {
+            if (!(fc - fc == 0.0)) flags |= ALILQR_FLAG_NONFINITE;
+            a.status[(size_t)p * ALILQR_STATUS_WORDS + 0] = n_inner;
+            a.status[(size_t)p * ALILQR_STATUS_WORDS + 1] = outer;
+            a.status[(size_t)p * ALILQR_STATUS_WORDS + 2] = (int32_t)flags;
+            a.status[(size_t)p * ALILQR_STATUS_WORDS + 3] = n_trials;
+          }
+        }
+        p = -1;
+      }
+    }
+  }
+}
+
+}  // namespace alilqr

@@ -1,0 +1,91 @@
+"""Synthetic problem sets of the solve path (the reference's demo configurations).
+
+Numbers follow the reference's drivers: S-curve goals cilqr/test.py:8-23, lateral
+weights and bounds cilqr/test.py:26-53, full-model weights al_ilqr_test.cc:33-35
+(the shipped cilqr/test_full.py:36-37 weights make the reference itself diverge),
+fast-solver setup cilqr/test_fast_full.py:31-60.
+"""
+import numpy as np
+
+from . import capi
+
+
+def s_curve_goals(v, dt, H, full):
+    """x = v t, y = 50 sin(0.1 t), heading and steering angle of that curve (cilqr/test.py:8-23)."""
+    t = np.arange(H + 1) * dt
+    x = v * t
+    y = 50 * np.sin(0.1 * t)
+    dy = 50 * 0.1 * np.cos(0.1 * t)
+    theta = np.arctan2(dy, v)
+    ddy = -50 * 0.1 * 0.1 * np.sin(0.1 * t)
+    curv = (v * ddy - dy * 0) / (v ** 2 + dy ** 2) ** 1.5
+    delta = np.arctan(curv * 1.0)
+    cols = [x, y, theta, delta]
+    if full:
+        cols += [np.full_like(t, v), np.zeros_like(t)]
+    return np.ascontiguousarray(np.stack(cols, axis=1))
+
+
+def lat_start_states(B, seed=0):
+    """x0 = (0, U(-1,1), U(-0.2,0.2), U(-0.05,0.05)), drawn per problem in that order."""
+    rng = np.random.default_rng(seed)
+    r = rng.uniform([-1.0, -0.2, -0.05], [1.0, 0.2, 0.05], size=(B, 3))
+    return np.ascontiguousarray(np.concatenate([np.zeros((B, 1)), r], axis=1))
+
+
+def full_start_states(B, seed):
+    """x0 = (0, U(-1,1), U(-0.1,0.1), 0, 10 + U(-1,1), 0)."""
+    rng = np.random.default_rng(seed)
+    r = rng.uniform([-1.0, -0.1, -1.0], [1.0, 0.1, 1.0], size=(B, 3))
+    x0 = np.zeros((B, 6))
+    x0[:, 1] = r[:, 0]
+    x0[:, 2] = r[:, 1]
+    x0[:, 4] = 10.0 + r[:, 2]
+    return x0
+
+
+def lat_legacy(B, H=50, seed=0, x0=None):
+    """ILQR + LatBicycleKinematicNode tracking the S-curve (BASELINE configs 1 and 2)."""
+    desc = capi.make_problem("lat", "legacy", H, B, L=1.0, dt=0.1, v=10.0)
+    Q = np.diag([1e-3, 1e-1, 1e1, 1e-9])
+    R = np.array([[50.0]])
+    cons = capi.pack_box([-1000, -1000, -2 * np.pi, -10.0], [1000, 1000, 2 * np.pi, 10.0], [-0.1], [0.1])
+    if x0 is None:
+        x0 = lat_start_states(B, seed)
+    return desc, np.ascontiguousarray(x0, dtype=np.float64), s_curve_goals(10.0, 0.1, H, False), Q, R, cons
+
+
+def full_legacy(model, B, H, seed, x0=None):
+    """ILQR + FullBicycle{Kinematic,Dynamic}Node with the converging (soft) weights."""
+    k = 0.0 if model == "kin" else 1e-3
+    desc = capi.make_problem(model, "legacy", H, B, L=3.0, dt=0.1, v=10.0, k=k)
+    Q = np.diag([1e-1, 1e-1, 1.0, 1e-9, 1e-6, 1e-6])
+    R = np.eye(2) * 10.0
+    cons = capi.pack_box([-1000, -1000, -2 * np.pi, -10, -100, -10.0], [1000, 1000, 2 * np.pi, 10, 100, 10.0],
+                         [-0.2, -1.0], [0.2, 1.0])
+    if x0 is None:
+        x0 = full_start_states(B, seed)
+    return desc, np.ascontiguousarray(x0, dtype=np.float64), s_curve_goals(10.0, 0.1, H, True), Q, R, cons
+
+
+def box_table(state_min, state_max, control_min, control_max):
+    """BoxConstraint as a linear table (cilqr/box_constrains.py:5-32): rows [I;-I;0;0] x + [0;0;I;-I] u + C."""
+    smin, smax, cmin, cmax = (np.asarray(a, dtype=np.float64) for a in (state_min, state_max, control_min, control_max))
+    n, m = smin.size, cmin.size
+    A = np.vstack([np.eye(n), -np.eye(n), np.zeros((2 * m, n))])
+    B = np.vstack([np.zeros((2 * n, m)), np.eye(m), -np.eye(m)])
+    C = np.concatenate([-smax, smin, -cmax, cmin])
+    return A, B, C
+
+
+def fast_box(B, H=50, seed=4, x0=None):
+    """FastILQR + FastBicycleNode + BoxConstraint with active x/y bounds (cilqr/test_fast_full.py:31-60)."""
+    A, Bm, C = box_table([-1000, -1000, -2 * np.pi, -10, -100, -10.0], [30, 10, 2 * np.pi, 10, 100, 10.0],
+                         [-0.2, -1.0], [0.2, 1.0])
+    desc = capi.make_problem("dyn_mid", "fast", H, B, L=1.0, dt=0.1, v=10.0, k=0.001, c=A.shape[0])
+    Q = np.diag([1e-1, 1e-1, 1.0, 1e-9, 1e-6, 1e-6]) * 1e3
+    R = np.eye(2) * 1e2
+    if x0 is None:
+        x0 = full_start_states(B, seed)
+    return desc, np.ascontiguousarray(x0, dtype=np.float64), s_curve_goals(10.0, 0.1, H, True), Q, R, \
+        capi.pack_linear(A, Bm, C)

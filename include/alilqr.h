@@ -1,0 +1,177 @@
+/*
+ * alilqr.h — C ABI of the MI355X batched augmented-Lagrangian iLQR solve path.
+ *
+ * Everything is plain C: POD descriptors, raw pointers, int32 status codes.
+ * All array arguments of the *_batch entry points are DEVICE pointers (HBM of
+ * the GPU that is current on the calling thread); the descriptor itself is a
+ * host struct.  Arrays at the boundary are row-major, one problem after the
+ * other, exactly the shapes the reference solver returns:
+ *     x (H+1, n), u (H, m)            cilqr/ilqr.py:16-17
+ * The library transposes into its own lane-contiguous layout internally.
+ *
+ * Each entry point names the reference interface it stands in for.
+ */
+#ifndef ALILQR_H
+#define ALILQR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALILQR_ABI_VERSION 1
+
+/* ---- vehicle model (node type) ------------------------------------------
+ * LAT      4 states / 1 control   cilqr/lat_bicycle_node.py:4-91
+ * KIN      6 / 2                  cilqr/full_bicycle_kinematic_node.py:4-105
+ * DYN      6 / 2, heading row of f_x evaluated at v      cilqr/full_bicycle_dynamic_node.py:61-108
+ * DYN_MID  6 / 2, heading row of f_x evaluated at v_mid  cilqr/fast_bicycle_node.py:56-139
+ *                 (same map as al_ilqr_cpp/model/new_bicycle_node.h:518-542)
+ * LAT_K    4 / 1 with the (1+k v^2) understeer factor    al_ilqr_cpp/model/new_lat_bicycle_node.h:27-58
+ */
+enum alilqr_model {
+  ALILQR_MODEL_LAT = 0,
+  ALILQR_MODEL_KIN = 1,
+  ALILQR_MODEL_DYN = 2,
+  ALILQR_MODEL_DYN_MID = 3,
+  ALILQR_MODEL_LAT_K = 4
+};
+
+/* ---- solver generation ---------------------------------------------------
+ * LEGACY  ILQR      cilqr/ilqr.py:6-192       box AL built into the node (lambda>=0, I_mu mask)
+ * FAST    FastILQR  cilqr/fast_ilqr.py:5-176  projection-form AL over a linear table (lambda<=0)
+ * NEW_AL  NewALILQR al_ilqr_cpp/new_al_ilqr.h:52-1220
+ */
+enum alilqr_mode {
+  ALILQR_MODE_LEGACY = 0,
+  ALILQR_MODE_FAST = 1,
+  ALILQR_MODE_NEW_AL = 2
+};
+
+enum alilqr_status {
+  ALILQR_OK = 0,
+  ALILQR_E_ARG = -1,       /* bad descriptor / null pointer / unsupported combination */
+  ALILQR_E_HIP = -2,       /* a HIP runtime call failed; see alilqr_last_error() */
+  ALILQR_E_NOMEM = -3,     /* workspace allocation failed */
+  ALILQR_E_NODEVICE = -4   /* no usable GPU */
+};
+
+/* bits of status word 2 (per problem) */
+#define ALILQR_FLAG_VIOL_OK   1u   /* stopped because violation < viol_stop           */
+#define ALILQR_FLAG_OUTER_CAP 2u   /* ran out of outer iterations                     */
+#define ALILQR_FLAG_NONFINITE 4u   /* final cost is NaN/Inf (the reference is silent) */
+
+/* Solver constants.  The reference hard-codes these as literals; the defaults
+ * returned by alilqr_default_params() are those literals, per generation:
+ *   cilqr/ilqr.py:27,92,117,151-174 ; cilqr/fast_ilqr.py:26,91,116,136-159 ;
+ *   al_ilqr_cpp/new_al_ilqr.h:668,1039,1045,1118,1188,1198-1211               */
+typedef struct alilqr_params {
+  int32_t max_outer;     /* outer (AL) iterations                         20 / 20 / arg */
+  int32_t max_inner;     /* inner (iLQR) iterations per outer             20 / 20 / arg */
+  double inner_tol;      /* |J_new - J_old| < tol stops the inner loop    1e-8 / 1e-8 / 1e-3 */
+  double viol_stop;      /* violation below this stops the outer loop     1e-3 / 1e-3 / arg */
+  double viol_lambda;    /* below: multiplier update, above: penalty x gain   1e-1 / 1e-1 / 5*viol_stop */
+  double mu_gain;        /* 8 / 8 / 100 */
+  double quu_reg;        /* added to diag(Quu) before inversion           1e-9 / 0 / 0 */
+  double alpha_min;      /* line search gives up when alpha <= this       1e-8 / 1e-8 / (10 halvings) */
+  double init_r;         /* control weight of the initial-guess LQR       20 */
+  double dv_gate;        /* NEW_AL only: skip the roll-out when |dV_lin| < gate   0.2 */
+} alilqr_params;
+
+/* One batch of independent problems that share model, horizon and tables. */
+typedef struct alilqr_problem {
+  int32_t abi_version;   /* ALILQR_ABI_VERSION */
+  int32_t model;         /* enum alilqr_model */
+  int32_t mode;          /* enum alilqr_mode  */
+  int32_t horizon;       /* H: number of controls; H+1 nodes */
+  int32_t n, m, c;       /* state, control, constraint-row counts (LEGACY: c = 2(n+m)) */
+  int32_t batch;         /* B problems */
+  int32_t goal_batch;    /* 1: all problems track the same goals; B: one goal list each */
+  int32_t table_nodes;   /* 1: Q,R,constraint table shared by all nodes; H+1: one per node */
+  double L, dt, v, k;    /* wheel base, step, (lat) speed, understeer factor */
+  alilqr_params prm;
+} alilqr_problem;
+
+/* Per-problem status: [0] inner iterations (backward passes) run, [1] outer
+ * iterations run, [2] ALILQR_FLAG_* bits, [3] line-search roll-outs run. */
+#define ALILQR_STATUS_WORDS 4
+
+/* ABI version of the loaded library (== ALILQR_ABI_VERSION of its build). */
+int32_t alilqr_abi_version(void);
+
+/* Text of the last failure on the calling thread ("" if none). */
+const char* alilqr_last_error(void);
+
+/* Number of HIP devices visible, or a negative alilqr_status. */
+int32_t alilqr_device_count(void);
+
+/* Fill *out with the reference literals of the given generation
+ * (cilqr/ilqr.py:151-174, cilqr/fast_ilqr.py:136-159, new_al_ilqr.h:1177-1211). */
+int32_t alilqr_default_params(int32_t mode, alilqr_params* out);
+
+/* Bytes of device scratch alilqr_solve_batch will hold for this descriptor. */
+int64_t alilqr_workspace_bytes(const alilqr_problem* p);
+
+/*
+ * Solve a batch.  Stands in for
+ *   ILQR(nodes).optimize(max_iters, tol)        cilqr/ilqr.py:151-175
+ *   FastILQR(nodes).optimize(max_iters, tol)    cilqr/fast_ilqr.py:136-160
+ *   NewALILQR<n,m>::optimize(outer, inner, tol) al_ilqr_cpp/new_al_ilqr.h:1177-1220
+ *                                               (bound at al_ilqr_cpp/ilqr_pybind.cc:25-33)
+ * applied to every problem of the batch.
+ *
+ *  in   x0     [B][n]                    nodes[0].state
+ *       goals  [goal_batch][H+1][n]      node.goal
+ *       Q      [table_nodes][n][n]       node.Q
+ *       R      [table_nodes][m][m]       node.R
+ *       cons   [table_nodes][...]        LEGACY: state_min[n] state_max[n] control_min[m] control_max[m]
+ *                                        FAST / NEW_AL: A[c][n] B[c][m] C[c]  (c(x,u) = A x + B u + C <= 0)
+ *  out  x_out  [B][H+1][n], u_out [B][H][m]      the (x, u) pair optimize() returns
+ *       node_x [B][H+1][n], node_u [B][H][m]     node.state / node.control after optimize() (may be NULL)
+ *       x_init [B][H+1][n], u_init [B][H][m]     the initial guess optimize() also returns (may be NULL)
+ *       cost   [B]                        compute_total_cost() after optimize()
+ *       viol   [B]                        last constraint violation measure (may be NULL)
+ *       lam    [B][H+1][c], mu [B]        final multipliers / penalty (may be NULL)
+ *       status [B][ALILQR_STATUS_WORDS]   (may be NULL)
+ *  stream      hipStream_t to enqueue on (NULL = default stream); the call
+ *              returns after enqueueing, outputs are valid once the stream drains.
+ * Returns ALILQR_OK or a negative alilqr_status; never throws.
+ */
+int32_t alilqr_solve_batch(const alilqr_problem* p,
+                           const double* x0, const double* goals,
+                           const double* Q, const double* R, const double* cons,
+                           double* x_out, double* u_out,
+                           double* node_x, double* node_u,
+                           double* x_init, double* u_init,
+                           double* cost, double* viol,
+                           double* lam, double* mu,
+                           int32_t* status, void* stream);
+
+/*
+ * Parallel-in-time linearisation / quadratisation of N = B*(H+1) independent
+ * (node, state, control) points: the per-node calls the reference makes at
+ * the top of its backward pass (cilqr/ilqr.py:70-77, cilqr/fast_ilqr.py:69-76):
+ *   node.dynamics(x,u), node.dynamics_jacobian(x,u), node.cost(),
+ *   node.cost_jacobian(), node.cost_hessian().
+ *  in   x [B][H+1][n], u [B][H+1][m] (terminal row = the node's control, normally 0),
+ *       lam [B][H+1][c], mu [B], goals/Q/R/cons as in alilqr_solve_batch
+ *  out  f [B][H+1][n], fx [B][H+1][n][n], fu [B][H+1][n][m], l [B][H+1],
+ *       lx [B][H+1][n], lu [B][H+1][m], lxx [B][H+1][n][n], luu [B][H+1][m][m]
+ *       (any output may be NULL)
+ */
+int32_t alilqr_linearize_batch(const alilqr_problem* p,
+                               const double* x, const double* u,
+                               const double* lam, const double* mu,
+                               const double* goals, const double* Q, const double* R, const double* cons,
+                               double* f, double* fx, double* fu, double* l,
+                               double* lx, double* lu, double* lxx, double* luu,
+                               void* stream);
+
+/* Release every cached device workspace of the calling process. */
+int32_t alilqr_release(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALILQR_H */

@@ -1,0 +1,48 @@
+/* oracle_internal.h — shared declarations of the CPU oracle (test infrastructure only). */
+#ifndef ORACLE_INTERNAL_H
+#define ORACLE_INTERNAL_H
+
+#include "alilqr_oracle.h"
+
+#define OR_NX 6
+#define OR_NU 2
+#define OR_NC 32
+#define OR_PI 3.141592653589793
+
+/* One trajectory node of the Python generations: model + cost + AL state. */
+typedef struct or_node {
+  int model, mode, n, m, c;
+  double L, dt, v, k;
+  const double *Q, *R;                 /* n x n, m x m */
+  double smin[OR_NX], smax[OR_NX], cmin[OR_NU], cmax[OR_NU];   /* legacy box */
+  const double *A, *B, *C;             /* linear table: c x n, c x m, c */
+  double goal[OR_NX], state[OR_NX], control[OR_NU];
+  double lam[OR_NC], mu, Imu[OR_NC];
+  double cc[OR_NC];                    /* cached constraint values (constraints.py: self.c) */
+} or_node;
+
+void om_mm(int r, int k, int c, const double* A, const double* B, double* C);
+void om_mtm(int r, int k, int c, const double* A, const double* B, double* C);
+int om_inv(int m, const double* Ain, double* Ainv);
+
+double or_wrap_py(double a);
+void or_node_init(or_node* nd, const alilqr_problem* p, int t,
+                  const double* goals, const double* Q, const double* R, const double* cons);
+void or_py_dynamics(const or_node* nd, const double* s, const double* u, double* next);
+void or_py_jacobian(const or_node* nd, const double* s, const double* u, double* A, double* B);
+
+/* NEW_AL generation (alilqr_oracle_new.c) */
+int32_t or_new_solve(const alilqr_problem* p,
+                     const double* x0, const double* goals,
+                     const double* Q, const double* R, const double* cons,
+                     double* x_out, double* u_out, double* node_x, double* node_u,
+                     double* x_init, double* u_init, double* cost, double* viol,
+                     double* lam, double* mu, int32_t* status, oracle_trace* trace);
+int32_t or_new_linearize(const alilqr_problem* p,
+                         const double* x, const double* u,
+                         const double* lam, const double* mu,
+                         const double* goals, const double* Q, const double* R, const double* cons,
+                         double* f, double* fx, double* fu, double* l,
+                         double* lx, double* lu, double* lxx, double* luu,
+                         double* cval, double* lam_new, double* xnorm);
+#endif

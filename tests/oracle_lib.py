@@ -1,0 +1,83 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ilqr_amd import capi
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+class Trace(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("length", C.c_int32),
+                ("iter_cost", C.POINTER(C.c_double)), ("trials", C.POINTER(C.c_int32))]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/liboracle.so is not built: run `make -C oracle`")
+        _LIB = C.CDLL(path)
+        _LIB.oracle_solve.restype = C.c_int32
+        _LIB.oracle_solve_batch.restype = C.c_int32
+        _LIB.oracle_linearize_batch.restype = C.c_int32
+        _LIB.oracle_max_threads.restype = C.c_int32
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def solve_batch(desc, x0, goals, Q, R, cons, threads=0, extras=True):
+    """Run the oracle on a batch; arrays are host numpy float64, C-contiguous."""
+    B, H, n, m, c = desc.batch, desc.horizon, desc.n, desc.m, desc.c
+    out = capi.alloc_outputs_numpy(B, H, n, m, c, extras)
+    args = [np.ascontiguousarray(a, dtype=np.float64) for a in (x0, goals, Q, R, cons)]
+    rc = lib().oracle_solve_batch(C.byref(desc), *[_p(a) for a in args],
+                                  _p(out["x"]), _p(out["u"]), _p(out.get("node_x")), _p(out.get("node_u")),
+                                  _p(out.get("x_init")), _p(out.get("u_init")), _p(out["cost"]), _p(out.get("viol")),
+                                  _p(out.get("lam")), _p(out.get("mu")), _p(out.get("status")), C.c_int32(threads))
+    if rc != 0:
+        raise RuntimeError(f"oracle_solve_batch failed: {rc}")
+    return out
+
+
+def solve_traced(desc, x0, goals, Q, R, cons, capacity=4096):
+    """One problem with the per-iteration trace."""
+    H, n, m, c = desc.horizon, desc.n, desc.m, desc.c
+    out = capi.alloc_outputs_numpy(1, H, n, m, c, True)
+    ic = np.zeros(capacity)
+    tr = np.zeros(capacity, dtype=np.int32)
+    trace = Trace(capacity, 0, ic.ctypes.data_as(C.POINTER(C.c_double)), tr.ctypes.data_as(C.POINTER(C.c_int32)))
+    args = [np.ascontiguousarray(a, dtype=np.float64) for a in (x0, goals, Q, R, cons)]
+    rc = lib().oracle_solve(C.byref(desc), *[_p(a) for a in args],
+                            _p(out["x"]), _p(out["u"]), _p(out["node_x"]), _p(out["node_u"]),
+                            _p(out["x_init"]), _p(out["u_init"]), _p(out["cost"]), _p(out["viol"]),
+                            _p(out["lam"]), _p(out["mu"]), _p(out["status"]), C.byref(trace))
+    if rc != 0:
+        raise RuntimeError(f"oracle_solve failed: {rc}")
+    out["iter_cost"] = ic[:trace.length].copy()
+    out["trials"] = tr[:trace.length].copy()
+    return out
+
+
+def linearize_batch(desc, x, u, lam, mu, goals, Q, R, cons):
+    B, H, n, m, c = desc.batch, desc.horizon, desc.n, desc.m, desc.c
+    N = B * (H + 1)
+    out = dict(f=np.zeros((B, H + 1, n)), fx=np.zeros((B, H + 1, n, n)), fu=np.zeros((B, H + 1, n, m)),
+               l=np.zeros((B, H + 1)), lx=np.zeros((B, H + 1, n)), lu=np.zeros((B, H + 1, m)),
+               lxx=np.zeros((B, H + 1, n, n)), luu=np.zeros((B, H + 1, m, m)),
+               cval=np.zeros((B, H + 1, c)), lam_new=np.zeros((B, H + 1, c)), xnorm=np.zeros((B, H + 1, n)))
+    args = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, u, lam, mu, goals, Q, R, cons)]
+    assert args[0].size == N * n and args[1].size == N * m
+    rc = lib().oracle_linearize_batch(C.byref(desc), *[_p(a) for a in args],
+                                      *[_p(out[k]) for k in ("f", "fx", "fu", "l", "lx", "lu", "lxx", "luu",
+                                                             "cval", "lam_new", "xnorm")])
+    if rc != 0:
+        raise RuntimeError(f"oracle_linearize_batch failed: {rc}")
+    return out
