@@ -250,11 +250,11 @@ int32_t alilqr_solve_batch(const alilqr_problem* p,
   Dims d;
   int32_t rc = check_problem(p, &d);
   if (rc != ALILQR_OK) return rc;
+  if (p->batch == 0) return ALILQR_OK;   /* an empty batch is valid and touches nothing */
   if (!x0 || !goals || !Q || !R || !cons || !x_out || !u_out || !cost) {
     set_err("x0, goals, Q, R, cons, x_out, u_out, cost must not be null");
     return ALILQR_E_ARG;
   }
-  if (p->batch == 0) return ALILQR_OK;
   int dev = 0;
   {
     int n = 0;
@@ -316,8 +316,8 @@ int32_t alilqr_linearize_batch(const alilqr_problem* p,
   Dims d;
   int32_t rc = check_problem(p, &d);
   if (rc != ALILQR_OK) return rc;
-  if (!x || !u || !lam || !mu || !goals || !Q || !R || !cons) { set_err("null input"); return ALILQR_E_ARG; }
   if (p->batch == 0) return ALILQR_OK;
+  if (!x || !u || !lam || !mu || !goals || !Q || !R || !cons) { set_err("null input"); return ALILQR_E_ARG; }
   {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { set_err("no HIP device is visible"); return ALILQR_E_NODEVICE; }

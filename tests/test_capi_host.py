@@ -1,0 +1,82 @@
+"""Host-side checks of the C ABI that need no GPU: the library loads, exports every
+declared symbol, mirrors the reference's literals and rejects bad descriptors."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ilqr_amd import capi, problems
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load_library()
+    header = open(os.path.join(ROOT, "include", "alilqr.h")).read()
+    declared = set(re.findall(r"\b(alilqr_[a-z_]+)\s*\(", header))
+    assert declared == set(capi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.alilqr_abi_version() == capi.ABI_VERSION
+
+
+@pytest.mark.parametrize("mode", ["legacy", "fast", "new_al"])
+def test_default_params_are_the_reference_literals(mode):
+    lib = capi.load_library()
+    got = capi.Params()
+    assert lib.alilqr_default_params(capi.MODES[mode], C.byref(got)) == 0
+    want = capi.default_params(mode)
+    for name, _ in capi.Params._fields_:
+        assert getattr(got, name) == getattr(want, name), name
+    if mode == "legacy":   # cilqr/ilqr.py:27,92,117,155-174
+        assert (want.max_outer, want.max_inner, want.inner_tol) == (20, 20, 1e-8)
+        assert (want.viol_stop, want.viol_lambda, want.mu_gain, want.quu_reg, want.init_r) == (1e-3, 1e-1, 8.0, 1e-9, 20.0)
+    if mode == "fast":     # cilqr/fast_ilqr.py:91
+        assert want.quu_reg == 0.0
+
+
+def test_bad_descriptors_are_rejected_before_any_device_work():
+    lib = capi.load_library()
+    desc, x0, goals, Q, R, cons = problems.lat_legacy(4)
+    null = [None] * 17
+
+    def call(d):
+        return lib.alilqr_solve_batch(C.byref(d), *null)
+
+    assert call(desc) == capi.E_ARG                       # null pointers
+    assert b"must not be null" in lib.alilqr_last_error()
+    bad = capi.make_problem("lat", "legacy", 50, 4, 1.0, 0.1, v=10.0)
+    bad.abi_version = 99
+    assert call(bad) == capi.E_ARG
+    bad = capi.make_problem("lat", "legacy", 50, 4, 1.0, 0.1, v=10.0)
+    bad.c = 7
+    assert call(bad) == capi.E_ARG
+    bad = capi.make_problem("lat", "legacy", 0, 4, 1.0, 0.1, v=10.0)
+    assert call(bad) == capi.E_ARG
+    bad = capi.make_problem("lat", "legacy", 50, 4, 1.0, 0.1, v=10.0)
+    bad.goal_batch = 3
+    assert call(bad) == capi.E_ARG
+    bad = capi.make_problem("dyn_mid", "legacy", 50, 4, 1.0, 0.1)
+    assert call(bad) == capi.E_ARG
+    assert lib.alilqr_workspace_bytes(C.byref(desc)) > 0
+    empty = capi.make_problem("lat", "legacy", 50, 0, 1.0, 0.1, v=10.0)
+    assert call(empty) == 0                               # an empty batch is valid and touches nothing
+
+
+def test_no_cpu_fallback_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from ilqr_amd import batch
+    desc, x0, goals, Q, R, cons = problems.lat_legacy(2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        batch.solve_batch(desc, x0, goals, Q, R, cons)
+
+
+def test_problem_generators_are_seeded():
+    a = problems.lat_start_states(8, 0)
+    b = problems.lat_start_states(16, 0)
+    assert np.array_equal(a, b[:8])
+    assert np.all(a[:, 0] == 0) and np.all(np.abs(a[:, 1]) <= 1) and np.all(np.abs(a[:, 2]) <= 0.2)

@@ -1,0 +1,76 @@
+"""The CPU oracle against vectors produced by the reference itself (tools/make_goldens.py).
+
+Tolerance: 1e-6 relative (the parity bar of the solve path) is asserted; the
+oracle actually reproduces the reference to ~1e-11 on every solve the
+reference itself reproduces from a start state moved by 1e-13 ("stable").
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle_lib as ol
+from ilqr_amd import capi
+
+TOL = 1e-6
+SETS = ["lat_legacy", "dyn_legacy", "kin_legacy", "fast_box", "fast_linear"]
+
+
+@pytest.mark.parametrize("name", SETS)
+def test_solver_matches_reference_on_stable_problems(name):
+    g = gu.load(name)
+    desc, x0, goals, Q, R, cons = gu.problem_from_golden(g)
+    out = ol.solve_batch(desc, x0, goals, Q, R, cons)
+    stable = g["stable"]
+    assert stable.sum() >= 3, "golden set holds too few reproducible solves"
+    for i in np.nonzero(stable)[0]:
+        for key in ("x", "u", "node_x", "node_u", "x_init", "u_init"):
+            assert gu.rel_err(out[key][i], g[key][i]) < TOL, (name, i, key)
+        assert abs(out["cost"][i] - g["cost"][i]) <= TOL * max(1.0, abs(g["cost"][i])), (name, i)
+        assert gu.rel_err(out["lam"][i], g["lam"][i]) < TOL, (name, i, "lam")
+        assert abs(out["mu"][i] - g["mu"][i, 0]) <= TOL * g["mu"][i, 0]
+        assert out["status"][i, 1] == g["n_outer"][i], (name, i, "outer iterations")
+        if name != "fast_box":
+            # fast_box: the reference's BLAS rounding moves a few accept/reject ties, results agree anyway
+            assert out["status"][i, 0] == g["n_inner"][i], (name, i, "inner iterations")
+
+
+def test_config1_headline_numbers():
+    """Single lat problem from x0 = 0: the numbers recorded from the reference run."""
+    g = gu.load("lat_legacy")
+    desc, x0, goals, Q, R, cons = gu.problem_from_golden(g, idx=[0])
+    assert np.all(x0 == 0)
+    out = ol.solve_batch(desc, x0, goals, Q, R, cons)
+    assert abs(out["cost"][0] - 47.857285341711346) < 1e-9
+    assert abs(out["viol"][0] - 3.2955216762931e-4) < 1e-12
+    assert np.allclose(out["u"][0, :5, 0], [0.10008025, 0.10006924, 0.10005885, 0.10004914, 0.10004014], atol=1e-8)
+    assert np.allclose(out["x"][0, 50], [43.2081793, 23.1946600, 0.417729303, -0.00697609280], atol=1e-7)
+
+
+@pytest.mark.parametrize("tag,model,mode", [("legacy_lat", "lat", "legacy"), ("legacy_kin", "kin", "legacy"),
+                                             ("legacy_dyn", "dyn", "legacy"), ("fast_box", "dyn_mid", "fast"),
+                                             ("fast_linear", "dyn_mid", "fast")])
+def test_node_functions_match_reference(tag, model, mode):
+    """dynamics, f_x, f_u, cost, l_x, l_u, l_xx, l_uu, constraints, multiplier update at random points."""
+    k = gu.load("nodes_kat")
+    pre = tag + "_"
+    X, U, LAM, MU = k[pre + "X"], k[pre + "U"], k[pre + "LAM"], k[pre + "MU"]
+    N = X.shape[0]
+    if mode == "legacy":
+        cons = capi.pack_box(k[pre + "state_min"], k[pre + "state_max"], k[pre + "control_min"], k[pre + "control_max"])
+        c = None
+        v = float(k[pre + "v"])
+    else:
+        cons = capi.pack_linear(k[pre + "A"], k[pre + "B"], k[pre + "C"])
+        c = k[pre + "A"].shape[0]
+        v = 0.0
+    # one "problem" per sample, horizon 1: node 0 carries the sample, node 1 is ignored
+    desc = capi.make_problem(model, mode, 1, N, float(k[pre + "L"]), float(k[pre + "dt"]), v=v, k=float(k[pre + "k"]), c=c)
+    n, m = desc.n, desc.m
+    goals = np.tile(k[pre + "goal"], (2, 1))
+    x = np.zeros((N, 2, n)); x[:, 0] = X
+    u = np.zeros((N, 2, m)); u[:, 0] = U
+    lam = np.zeros((N, 2, desc.c)); lam[:, 0] = LAM
+    out = ol.linearize_batch(desc, x, u, lam, MU, goals, k[pre + "Q"], k[pre + "R"], cons)
+    for key, okey in (("f", "f"), ("fx", "fx"), ("fu", "fu"), ("l", "l"), ("lx", "lx"), ("lu", "lu"),
+                      ("lxx", "lxx"), ("luu", "luu"), ("cons", "cval"), ("lam_new", "lam_new")):
+        assert gu.rel_err(out[okey][:, 0], k[pre + key]) < 1e-12, (tag, key)
