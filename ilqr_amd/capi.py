@@ -115,6 +115,12 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise LibraryMissing(f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(needs hipcc).  There is no CPU fallback for the solve path.")
+    # torch ships its own HIP runtime (same SONAME); import it first so that the library binds to the
+    # runtime that owns the tensors' device pointers instead of pulling a second copy into the process
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.alilqr_abi_version.restype = C.c_int32
     lib.alilqr_last_error.restype = C.c_char_p

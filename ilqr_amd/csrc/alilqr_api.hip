@@ -290,6 +290,7 @@ int32_t alilqr_solve_batch(const alilqr_problem* p,
   ka.trj = (double*)(base + pl.trj); ka.kk = (double*)(base + pl.kk);
   ka.lin = (double*)(base + pl.lin); ka.lamw = (double*)(base + pl.lam);
   ka.counter = (unsigned int*)(base + pl.counter);
+  ka.prof = (unsigned long long*)(base + pl.counter + 128);   // zeroed with the counter; read by profiling builds
   const int waves = pl.NG * pl.G / 64;
 
   if (p->mode == ALILQR_MODE_LEGACY) {
@@ -343,6 +344,17 @@ int32_t alilqr_linearize_batch(const alilqr_problem* p,
   HIP_TRY(hipGetLastError());
   return ALILQR_OK;
 }
+
+#ifdef ALILQR_PROF
+/* profiling builds only: copy the 9 phase counters of the last solve on this device to the host */
+int32_t alilqr_prof_read(unsigned long long* out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || !g_ws[dev].ptr) return ALILQR_E_HIP;
+  if (hipDeviceSynchronize() != hipSuccess) return ALILQR_E_HIP;
+  if (hipMemcpy(out, (char*)g_ws[dev].ptr + 128, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return ALILQR_E_HIP;
+  return ALILQR_OK;
+}
+#endif
 
 int32_t alilqr_release(void) {
   std::lock_guard<std::mutex> lk(g_mu);

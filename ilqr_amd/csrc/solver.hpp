@@ -35,6 +35,16 @@
 
 namespace alilqr {
 
+#ifdef ALILQR_PROF
+#define PROF_DECL unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_MARK(i) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += t_ - prof_t0; prof_t0 = t_; }
+#define PROF_FLUSH(a) if (lane == 0 && (a).prof) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd((a).prof + i_, prof_acc[i_]); atomicAdd((a).prof + 8, 1ull); }
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#define PROF_FLUSH(a)
+#endif
+
 struct KArgs {
   int B, NG, H, C, goal_batch, table_nodes;
   ModelConst mc;
@@ -44,6 +54,7 @@ struct KArgs {
   int32_t* status;
   double *trj, *kk, *lin, *lamw;
   unsigned int* counter;
+  unsigned long long* prof;   // optional phase cycle counters (profiling builds only)
 };
 
 // ---- lane-group primitives ---------------------------------------------------
@@ -573,7 +584,9 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
     return total;
   };
 
+  PROF_DECL
   for (;;) {
+    PROF_MARK(7)
     // ================= problem switch: pull + initial guess =================
     if (p < 0 && !drained) {
       int np = 0;
@@ -707,6 +720,7 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
         __threadfence_block();
       }
     }
+    PROF_MARK(0)
     // every group of the wave idle and nothing left to pull: done
     if (__ballot(p >= 0) == 0ull) break;
 
@@ -721,6 +735,7 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
       const int np_ = 1 - cur_par;              // parity the candidates are written to
       const size_t myslot = gid * G + gl;
 
+      PROF_MARK(1)
       // ================= P1: linearise + quadratise, parallel in time =================
       for (int t = gl; t <= H; t += G) {
         double x[N], u[M];
@@ -742,6 +757,7 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
       }
       __threadfence_block();
 
+      PROF_MARK(2)
       // ================= P2: backward Riccati sweep =================
       {
         double Vx[N], Vxx[N][N];
@@ -775,6 +791,7 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
       }
       __threadfence_block();
 
+      PROF_MARK(3)
       // ================= P3: roll-outs, one line-search trial per lane =================
       double new_cost = old_cost;
       int win_lane = -1;
@@ -858,6 +875,7 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
       if (win_lane >= 0) { cur_lane = win_lane; cur_par = np_; }
       __threadfence_block();
 
+      PROF_MARK(4)
       // ================= P4: inner / outer bookkeeping (ilqr.py:158-174) =================
       ++n_inner; ++inner;
       const bool brk = fabs(new_cost - old_cost) < a.prm.inner_tol;
@@ -929,8 +947,10 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
         }
         p = -1;
       }
+      PROF_MARK(5)
     }
   }
+  PROF_FLUSH(a)
 }
 
 }  // namespace alilqr

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Development aid: per-phase cycle breakdown of the solve kernel.
+
+Builds a profiling variant of the library (-DALILQR_PROF: s_memtime stamps at
+phase boundaries, summed over waves) next to the product one and runs the
+bench workload once.  Run on the GPU box:  python tools/phase_profile.py [lanes]
+"""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+def build():
+    out = os.path.join(ROOT, "ilqr_amd", "csrc", "libalilqr_hip_prof.so")
+    src = os.path.join(ROOT, "ilqr_amd", "csrc", "alilqr_api.hip")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(os.path.join(ROOT, "ilqr_amd", "csrc", f)) for f in ("alilqr_api.hip", "solver.hpp", "models.hpp")):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                        "-DALILQR_PROF", "-o", out, src], check=True)
+    return out
+
+def main():
+    path = build()
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        return
+    from ilqr_amd import capi, batch, problems
+    capi.LIB_PATH = path
+    lib = capi.load_library()
+    import torch
+    B = int(os.environ.get("B", "4096"))
+    desc, x0, goals, Q, R, cons = problems.lat_legacy(B, 50, seed=0)
+    s = batch.BatchSolver(desc, x0, goals, Q, R, cons)
+    s.run(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); o = s.run(); e1.record(); torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 9)()
+    assert lib.alilqr_prof_read(buf) == 0
+    v = np.array(list(buf), dtype=np.float64)
+    names = ["pull+init", "outer-start cost", "P1 linearise", "P2 riccati", "P3 rollouts", "P4 bookkeeping", "-", "loop top"]
+    waves = v[8]
+    tot = v[:8].sum()
+    st = o["status"].cpu().numpy()
+    print(f"lanes={os.environ.get('ALILQR_LANES','auto')} B={B} kernel {e0.elapsed_time(e1):.1f} ms  waves {int(waves)}  mean wave busy {tot/waves/1e6:.1f} Mcycles  mean inner {st[:,0].mean():.1f}")
+    for n, x in zip(names, v[:8]):
+        print(f"  {n:18s} {100*x/tot:6.2f} %   {x/waves/1e6:8.2f} Mcyc/wave")
+
+if __name__ == "__main__":
+    main()
