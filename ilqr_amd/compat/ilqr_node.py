@@ -1,0 +1,2 @@
+"""Flat module name of the reference (cilqr/ilqr_node.py): put this directory on sys.path to run its scripts unchanged."""
+from ilqr_amd.nodes import ILQRNode  # noqa: F401

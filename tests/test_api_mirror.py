@@ -1,0 +1,120 @@
+"""Host logic of the reference-shaped Python classes (no GPU): signatures, validation, data packing."""
+import copy
+
+import numpy as np
+import pytest
+
+from ilqr_amd import capi, problems
+from ilqr_amd.nodes import (BoxConstraint, Constraints, FastBicycleNode, FastILQRNode, FullBicycleDynamicNode,
+                            FullBicycleKinematicNode, ILQRNode, LatBicycleKinematicNode, LinearConstraints)
+from ilqr_amd.solvers import ILQR, FastILQR
+
+
+def lat_nodes(H=5):
+    goals = problems.s_curve_goals(10.0, 0.1, H, False)
+    sb = np.array([[-1000, -1000, -2 * np.pi, -10], [1000, 1000, 2 * np.pi, 10]])
+    cb = np.array([[-0.1], [0.1]])
+    return [LatBicycleKinematicNode(L=1, dt=0.1, v=10, state_bounds=sb, control_bounds=cb, goal=g,
+                                    Q=np.diag([1e-3, 1e-1, 1e1, 1e-9]), R=np.array([[50]])) for g in goals]
+
+
+def test_setters_validate_like_the_reference():
+    nd = lat_nodes()[0]
+    assert (nd.state_dim, nd.control_dim, nd.constraint_dim) == (4, 1, 10)
+    with pytest.raises(ValueError, match="Invalid state dimension"):
+        nd.state = np.zeros(3)
+    with pytest.raises(ValueError, match="Invalid control dimension"):
+        nd.control = np.zeros(2)
+    with pytest.raises(ValueError, match="Invalid goal dimension"):
+        nd.goal = np.zeros(5)
+    nd.state = [1, 2, 3, 4]
+    assert isinstance(nd.state, np.ndarray)
+    assert issubclass(LatBicycleKinematicNode, ILQRNode) and issubclass(FastBicycleNode, FastILQRNode)
+    assert issubclass(BoxConstraint, LinearConstraints) and issubclass(LinearConstraints, Constraints)
+
+
+def test_legacy_node_data_helpers():
+    nd = lat_nodes()[0]
+    nd.state = np.array([1.0, 2.0, 4.0, 0.2])        # theta = 4 wraps to 4 - 2 pi
+    nd.control = np.array([0.3])
+    c = nd.constraints()
+    assert abs(nd.state[2] - (4.0 - 2 * np.pi)) < 1e-12
+    assert c.shape == (10,) and abs(c[8] - 0.2) < 1e-15 and abs(c[9] + 0.4) < 1e-15
+    nd.set_lambda(np.zeros(10)); nd.set_mu(3.0)
+    nd.update_Imu()
+    assert np.array_equal(np.diag(nd.Imu) != 0, c > 0)
+    nd.update_lambda()
+    assert np.allclose(nd.get_lambda(), np.maximum(0, 3.0 * c))
+    Jx, Ju = nd.constraint_jacobian()
+    assert Jx.shape == (10, 4) and Ju.shape == (10, 1) and Ju[8, 0] == 1 and Ju[9, 0] == -1
+    assert not nd.is_state_within_constraints()
+    assert np.array_equal(nd.constraint_table(), capi.pack_box(nd.state_min, nd.state_max, nd.control_min, nd.control_max))
+
+
+def test_constraints_scalar_helpers_follow_the_reference_formulas():
+    rng = np.random.default_rng(0)
+    A, B, C = rng.normal(size=(5, 6)), rng.normal(size=(5, 2)), rng.normal(size=5)
+    cons = LinearConstraints(A, B, C)
+    cons.lambda_ = -np.abs(rng.normal(size=5)); cons.mu = 2.5
+    x, u = rng.normal(size=6), rng.normal(size=2)
+    c = A @ x + B @ u + C
+    f = cons.lambda_ - 2.5 * c
+    lp = np.minimum(f, 0)
+    assert abs(cons.augmented_lagrangian_cost(x, u) - 0.5 / 2.5 * (lp @ lp - cons.lambda_ @ cons.lambda_)) < 1e-14
+    dx, du = cons.augmented_lagrangian_jacobian(x, u)
+    pj = np.diag((f <= 0).astype(float))
+    assert np.allclose(dx, -(pj @ A).T @ lp) and np.allclose(du, -(pj @ B).T @ lp)
+    hx, hu, hxu = cons.augmented_lagrangian_hessian(x, u)
+    assert np.allclose(hx, 2.5 * (pj @ A).T @ (pj @ A)) and hxu.shape == (6, 2) and hu.shape == (2, 2)
+    assert abs(cons.max_violation(x, u) - max(0, c.max())) < 1e-15
+    cons.update_lambda()
+    assert np.allclose(cons.lambda_, lp)
+    box = BoxConstraint(-np.ones(3), np.ones(3), -np.ones(2) / 2, np.ones(2) / 2)
+    assert box.A.shape == (10, 3) and box.B.shape == (10, 2) and np.allclose(box.C, [-1, -1, -1, -1, -1, -1, -.5, -.5, -.5, -.5])
+
+
+def test_solver_describes_the_node_list():
+    nodes = lat_nodes(6)
+    s = ILQR(nodes)
+    assert s.horizon == 6
+    desc, goals, Q, R, cons = s._describe(3, 20, 1e-8)
+    assert (desc.model, desc.mode, desc.horizon, desc.batch, desc.table_nodes, desc.c) == (0, 0, 6, 3, 1, 10)
+    assert goals.shape == (1, 7, 4) and Q.shape == (1, 4, 4) and cons.shape == (1, 10)
+    assert desc.prm.max_inner == 20 and desc.prm.quu_reg == 1e-9
+    nodes[2].Q = np.diag([1.0, 1.0, 1.0, 1.0])              # one node differs -> per-node tables
+    desc, goals, Q, R, cons = s._describe(1, 20, 1e-8)
+    assert desc.table_nodes == 7 and Q.shape == (7, 4, 4)
+    nodes[3].dt = 0.2
+    with pytest.raises(ValueError, match="same on every node"):
+        s._describe(1, 20, 1e-8)
+    with pytest.raises(TypeError):
+        FastILQR(lat_nodes(3))._describe(1, 20, 1e-8)
+    with pytest.raises(ValueError, match="Invalid state dimension"):
+        ILQR(lat_nodes(3)).solve_batch(np.zeros((2, 5)))
+
+
+def test_fast_node_packs_its_constraint_object():
+    goals = problems.s_curve_goals(10.0, 0.1, 4, True)
+    box = BoxConstraint(np.array([-1000, -1000, -7, -10, -100, -10.0]), np.array([30, 10, 7, 10, 100, 10.0]),
+                        np.array([-0.2, -1.0]), np.array([0.2, 1.0]))
+    nodes = [FastBicycleNode(1.0, 0.1, 0.001, g, np.eye(6), np.eye(2), copy.deepcopy(box)) for g in goals]
+    desc, g, Q, R, cons = FastILQR(nodes)._describe(1, 20, 1e-8)
+    assert (desc.model, desc.mode, desc.c) == (3, 1, 16) and cons.shape == (1, 16 * 9)
+    assert nodes[0].constraints_obj is not nodes[1].constraints_obj
+    nodes[0].state = np.array([31.0, 0, 0, 0, 10, 0])
+    assert nodes[0].constraints[0] == 1.0                  # x - x_max
+    eq = LinearConstraints(np.zeros((1, 6)), np.zeros((1, 2)), np.zeros(1), is_equality=True)
+    with pytest.raises(NotImplementedError):
+        FastBicycleNode(1.0, 0.1, 0.0, goals[0], np.eye(6), np.eye(2), eq).constraint_table()
+
+
+def test_flat_module_names_of_the_reference_import(monkeypatch):
+    import os, sys, importlib
+    compat = os.path.join(os.path.dirname(capi.__file__), "compat")
+    monkeypatch.syspath_prepend(compat)
+    for mod, name in (("lat_bicycle_node", "LatBicycleKinematicNode"), ("ilqr", "ILQR"), ("fast_ilqr", "FastILQR"),
+                      ("box_constrains", "BoxConstraint"), ("fast_bicycle_node", "FastBicycleNode")):
+        sys.modules.pop(mod, None)
+        m = importlib.import_module(mod)
+        assert hasattr(m, name)
+        sys.modules.pop(mod, None)
