@@ -93,8 +93,18 @@ int pick_group(const alilqr_problem* p) {
 
 struct Plan {
   int G, NG;
-  size_t trj, kk, lin, lam, counter, total;   // byte offsets / total
+  size_t trj, blk, counter, total;   // byte offsets / total
 };
+
+size_t block_doubles_for(const alilqr_problem* p) {
+  using namespace alilqr;
+  const int H = p->horizon, C = p->c;
+  if (p->mode == ALILQR_MODE_LEGACY) {
+    if (p->model == ALILQR_MODEL_LAT) return block_doubles<Model<ALILQR_MODEL_LAT>, ALILQR_MODE_LEGACY>(H, C);
+    return block_doubles<Model<ALILQR_MODEL_KIN>, ALILQR_MODE_LEGACY>(H, C);
+  }
+  return block_doubles<Model<ALILQR_MODEL_DYN_MID>, ALILQR_MODE_FAST>(H, C);
+}
 
 Plan make_plan(const alilqr_problem* p, const Dims& d) {
   Plan pl{};
@@ -112,9 +122,7 @@ Plan make_plan(const alilqr_problem* p, const Dims& d) {
   size_t off = 0;
   pl.counter = off; off = up(off + 256);
   pl.trj = off; off = up(off + sizeof(double) * 2 * T * (size_t)pl.NG * pl.G);
-  pl.kk = off; off = up(off + sizeof(double) * H * (M * N + M) * (size_t)pl.NG);
-  pl.lin = off; off = up(off + sizeof(double) * (H + 1) * d.E * (size_t)pl.NG);
-  pl.lam = off; off = up(off + sizeof(double) * (H + 1) * (size_t)p->c * (size_t)pl.NG);
+  pl.blk = off; off = up(off + sizeof(double) * block_doubles_for(p) * (size_t)pl.NG);
   pl.total = off;
   return pl;
 }
@@ -287,8 +295,7 @@ int32_t alilqr_solve_batch(const alilqr_problem* p,
   ka.x_out = x_out; ka.u_out = u_out; ka.node_x = node_x; ka.node_u = node_u;
   ka.x_init = x_init; ka.u_init = u_init; ka.cost = cost; ka.viol = viol; ka.lam = lam; ka.mu = mu;
   ka.status = status;
-  ka.trj = (double*)(base + pl.trj); ka.kk = (double*)(base + pl.kk);
-  ka.lin = (double*)(base + pl.lin); ka.lamw = (double*)(base + pl.lam);
+  ka.trj = (double*)(base + pl.trj); ka.blk = (double*)(base + pl.blk);
   ka.counter = (unsigned int*)(base + pl.counter);
   ka.prof = (unsigned long long*)(base + pl.counter + 128);   // zeroed with the counter; read by profiling builds
   const int waves = pl.NG * pl.G / 64;

@@ -38,6 +38,10 @@ __device__ __forceinline__ double wrap_py(double a) {
   return r - kPi;
 }
 
+// the argument is known to be an output of wrap_py (a fixed point of it): nothing to do
+template <bool WRAPPED>
+__device__ __forceinline__ double wrap_in(double a) { return WRAPPED ? a : wrap_py(a); }
+
 struct ModelConst {
   double L, dt, v, k;
 };
@@ -67,9 +71,10 @@ struct Lat4Base {
 
 template <>
 struct Model<ALILQR_MODEL_LAT> : Lat4Base {
+  template <bool WRAPPED = false>
   __device__ static void step(const ModelConst& mc, const double* x, const double* u, double* xn) {
     const double v = mc.v, dt = mc.dt, L = mc.L;
-    double th = wrap_py(x[2]), de = wrap_py(x[3]);
+    double th = wrap_in<WRAPPED>(x[2]), de = wrap_in<WRAPPED>(x[3]);
     double s1, c1;
     sincos(th, &s1, &c1);
     double k1[4] = {v * c1, v * s1, v * tan(de) / L, u[0]};
@@ -86,9 +91,10 @@ struct Model<ALILQR_MODEL_LAT> : Lat4Base {
     xn[2] = wrap_py(xn[2]);
     xn[3] = wrap_py(xn[3]);
   }
+  template <bool WRAPPED = false>
   __device__ static void jac(const ModelConst& mc, const double* x, const double* uc, double* a, double* b) {
     const double v = mc.v, dt = mc.dt, L = mc.L;
-    double th = wrap_py(x[2]), de = wrap_py(x[3]);
+    double th = wrap_in<WRAPPED>(x[2]), de = wrap_in<WRAPPED>(x[3]);
     double u = uc[0];
     double td = tan(de);
     double tm = th + 0.5 * dt * v * td / L;
@@ -123,8 +129,9 @@ struct Full6Base {
 
 template <int MODEL>
 struct Full6 : Full6Base {
+  template <bool WRAPPED>
   __device__ static void cont(const ModelConst& mc, const double* s, const double* u, double* out) {
-    double th = wrap_py(s[2]), de = wrap_py(s[3]);
+    double th = wrap_in<WRAPPED>(s[2]), de = wrap_in<WRAPPED>(s[3]);
     double v = s[4], acc = s[5];
     double sn, cs;
     sincos(th, &sn, &cs);
@@ -138,21 +145,23 @@ struct Full6 : Full6Base {
     out[4] = acc;
     out[5] = u[1];
   }
+  template <bool WRAPPED = false>
   __device__ static void step(const ModelConst& mc, const double* x, const double* u, double* xn) {
     double k1[6], k2[6], mid[6];
-    cont(mc, x, u, k1);
+    cont<WRAPPED>(mc, x, u, k1);
     double hdt = 0.5 * mc.dt;
 #pragma unroll
     for (int i = 0; i < 6; ++i) mid[i] = x[i] + hdt * k1[i];
-    cont(mc, mid, u, k2);
+    cont<false>(mc, mid, u, k2);
 #pragma unroll
     for (int i = 0; i < 6; ++i) xn[i] = x[i] + mc.dt * k2[i];
     xn[2] = wrap_py(xn[2]);
     xn[3] = wrap_py(xn[3]);
   }
+  template <bool WRAPPED = false>
   __device__ static void jac(const ModelConst& mc, const double* x, const double* uc, double* a, double* b) {
     const double dt = mc.dt, L = mc.L, k = mc.k;
-    double theta = wrap_py(x[2]), delta = wrap_py(x[3]);
+    double theta = wrap_in<WRAPPED>(x[2]), delta = wrap_in<WRAPPED>(x[3]);
     double v = x[4], acc = x[5], u1 = uc[0];
     double dt2 = dt * dt;
     double tan_delta = tan(delta);

@@ -18,14 +18,17 @@
 // so groups that are in different outer iterations, or on different problems,
 // still execute the heavy phases together.
 //
-// Data layout in HBM (fp64).  Workspace arrays are "element-major, group-minor"
-//   kk   [H*(M*N+M)]   [NG]      feedback K_t and feed-forward k_t
-//   lin  [(H+1)*E]     [NG]      per-node f_x, f_u (variable entries), l_x, l_u, l_xx, l_uu
-//   lam  [(H+1)*C]     [NG]      multipliers
-//   trj  [2][T]        [NG*G]    candidate trajectories, one slot per lane and parity
-// so a wave access to one element is one contiguous run of doubles.  The
-// current trajectory of a problem is the pair (slot lane, parity) of the last
-// accepted roll-out; nothing is copied on acceptance.
+// Data layout in HBM (fp64).
+//   blk  one block per group: H+1 step records  x_t | u_t | K_t | k_t | goal_t | lambda_t
+//        followed by H+1 linearisation records  f_x, f_u entries | l_x | l_u | l_xx | l_uu.
+//        G > 1: the block is contiguous (problem-major), so a sequential sweep reads one
+//        short run of doubles per step from one base address; G = 1: element-major /
+//        group-minor, so the 64 problems of a wave read one contiguous run per element.
+//   trj  [2][T][NG*G]  candidate trajectories, one slot per lane and parity, lane-minor:
+//        the roll-out stores of a wave are contiguous 512-B runs.
+// The current trajectory of a problem is the pair (slot lane, parity) of the last
+// accepted roll-out; nothing is copied on acceptance.  Sequential sweeps (P2, P3)
+// load the record of the next step before computing the current one.
 //
 // Reference control flow restated here: cilqr/ilqr.py:11-192 (LEGACY, including
 // the array aliasing of forward() after its first rejected step, :137-138) and
@@ -52,7 +55,7 @@ struct KArgs {
   const double *x0, *goals, *Q, *R, *cons;
   double *x_out, *u_out, *node_x, *node_u, *x_init, *u_init, *cost, *viol, *lam, *mu;
   int32_t* status;
-  double *trj, *kk, *lin, *lamw;
+  double *trj, *blk;
   unsigned int* counter;
   unsigned long long* prof;   // optional phase cycle counters (profiling builds only)
 };
@@ -164,17 +167,16 @@ __device__ __forceinline__ void inv_small(const double (&Qm)[M][M], double (&Qi)
 }
 
 // One step of the backward recursion (cilqr/ilqr.py:85-98).
-template <class MD>
+template <class MD, class FLx, class FLu, class FLxx, class FLuu>
 __device__ __forceinline__ void riccati_step(const double (&S)[MD::N][MD::N], const double (&Bm)[MD::N][MD::M],
-                                             const double* lx, const double* lu, const double* lxx, const double* luu,
-                                             size_t stride, double reg,
+                                             FLx lx, FLu lu, FLxx lxx, FLuu luu, double reg,
                                              double (&Vx)[MD::N], double (&Vxx)[MD::N][MD::N],
                                              double (&K)[MD::M][MD::N], double (&kf)[MD::M]) {
   constexpr int N = MD::N, M = MD::M;
   double Qx[N], Qu[M];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    double acc = lx[i * stride] + Vx[i];
+    double acc = lx(i) + Vx[i];
 #pragma unroll
     for (int k = 0; k < N; ++k)
       if (s_nz<MD>(k, i)) acc = fma(S[k][i], Vx[k], acc);
@@ -182,7 +184,7 @@ __device__ __forceinline__ void riccati_step(const double (&S)[MD::N][MD::N], co
   }
 #pragma unroll
   for (int a = 0; a < M; ++a) {
-    double acc = lu[a * stride];
+    double acc = lu(a);
 #pragma unroll
     for (int k = 0; k < N; ++k)
       if (b_nz<MD>(k, a)) acc = fma(Bm[k][a], Vx[k], acc);
@@ -204,7 +206,7 @@ __device__ __forceinline__ void riccati_step(const double (&S)[MD::N][MD::N], co
     }
 #pragma unroll
     for (int b = 0; b < M; ++b) {
-      double acc = luu[(a * M + b) * stride];
+      double acc = luu(a, b);
 #pragma unroll
       for (int k = 0; k < N; ++k)
         if (b_nz<MD>(k, a)) acc = fma(Bm[k][a], T[k][b], acc);
@@ -260,7 +262,7 @@ __device__ __forceinline__ void riccati_step(const double (&S)[MD::N][MD::N], co
   for (int i = 0; i < N; ++i)
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      double acc = lxx[(i * N + j) * stride] + W[i][j];
+      double acc = lxx(i, j) + W[i][j];
 #pragma unroll
       for (int k = 0; k < N; ++k)
         if (s_nz<MD>(k, i)) acc = fma(S[k][i], W[k][j], acc);
@@ -518,13 +520,46 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
 // ---------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------
+// Per-step record of a problem, contiguous in the group's block:
+//   x_t | u_t | K_t | k_t | goal_t | lambda_t        (RecLayout)
+// followed (after all H+1 records) by the per-node linearisation records:
+//   LEGACY  f_x entries | f_u entries | l_x | l_u | diagonal AL terms of l_xx | of l_uu
+//   FAST    f_x entries | f_u entries | l_x | l_u | l_xx (N x N) | l_uu (M x M)
+template <class MD>
+struct RecLayout {
+  static constexpr int N = MD::N, M = MD::M;
+  static constexpr int rx = 0, ru = rx + N, rK = ru + M, rk = rK + M * N, rg = rk + M, rl = rg + N;
+};
+template <class MD, int MODE>
+struct NodeRec {
+  static constexpr int N = MD::N, M = MD::M;
+  static constexpr bool LEGACY = (MODE == ALILQR_MODE_LEGACY);
+  static constexpr int HX = LEGACY ? N : N * N, HU = LEGACY ? M : M * M;
+  static constexpr int oA = 0, oB = oA + MD::NA, oLx = oB + MD::NB, oLu = oLx + N, oHx = oLu + M, oHu = oHx + HX,
+                       E = (oHu + HU + 1) & ~1;
+};
+
+// doubles of one group's block (host and device must agree)
+template <class MD, int MODE>
+__host__ __device__ inline size_t block_doubles(int H, int C) {
+  const size_t RS = (size_t)((RecLayout<MD>::rl + C + 1) & ~1);
+  return (size_t)(H + 1) * (RS + NodeRec<MD, MODE>::E);
+}
+
+#ifndef ALILQR_MINW_N4
+#define ALILQR_MINW_N4 2   // waves per SIMD the 4-state kernels are compiled for (256 registers per lane)
+#endif
 template <int MODEL, int MODE, int G>
-__global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
+__global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) void solve_kernel(KArgs a) {
   using MD = Model<MODEL>;
   using OPS = NodeOps<MODEL, MODE>;
   using LL = LinLayout<MD>;
+  using RL = RecLayout<MD>;
+  using NR = NodeRec<MD, MODE>;
   constexpr int N = MD::N, M = MD::M;
   constexpr bool LEGACY = (MODE == ALILQR_MODE_LEGACY);
+  constexpr bool PM = (G > 1);                         // block layout: problem-major (contiguous) or element-major
+  constexpr int CL = LEGACY ? 2 * (N + M) : 1;         // multipliers held in registers (LEGACY only)
 
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);                       // lane inside the group
@@ -536,12 +571,12 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
   const size_t NG = (size_t)a.NG, LT = NG * G;
   const int XS = (H + 1) * N, US = H * M, T = XS + US;
   const ModelConst mc = a.mc;
-  const int KS = M * N + M;   // doubles of (K_t, k_t)
+  const int RS = (RL::rl + C + 1) & ~1;
+  const size_t ES = PM ? (size_t)1 : NG;               // element stride inside the block
+  double* const blk = a.blk + (PM ? gid * block_doubles<MD, MODE>(H, C) : gid);
+  double* const linb = blk + (size_t)(H + 1) * RS * ES;
 
   double* const trj = a.trj;
-  double* const kk = a.kk + gid;
-  double* const lin = a.lin + gid;
-  double* const lamw = a.lamw + gid;
   const int cw = LEGACY ? (2 * N + 2 * M) : C * (N + M + 1);   // doubles per constraint table
 
   // number of line-search trials the reference can make: alpha = 1, 1/2, ... while alpha > alpha_min
@@ -555,29 +590,49 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
   double mu = 1.0, old_cost = 0.0, viol = 0.0;
   int outer = 0, inner = 0, n_inner = 0, n_trials = 0;
   bool outer_start = false;
-  const double* goals = a.goals;
 
   auto trj_at = [&](int par, int off, size_t slot_lane) -> double* {
     return trj + ((size_t)par * T + off) * LT + slot_lane;
   };
+  auto rec = [&](int t) -> double* { return blk + (size_t)t * RS * ES; };
+  auto lrec = [&](int t) -> double* { return linb + (size_t)t * NR::E * ES; };
   auto tabQ = [&](int t) { return a.Q + (size_t)((a.table_nodes > 1) ? t : 0) * N * N; };
   auto tabR = [&](int t) { return a.R + (size_t)((a.table_nodes > 1) ? t : 0) * M * M; };
   auto tabC = [&](int t) { return a.cons + (size_t)((a.table_nodes > 1) ? t : 0) * cw; };
 
+  // node t of the current trajectory (slot of the last accepted roll-out)
+  auto load_node = [&](int t, double* x, double* u) {
+    const size_t cs = gid * G + cur_lane;
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = *trj_at(cur_par, t * N + i, cs);
+#pragma unroll
+    for (int j = 0; j < M; ++j) u[j] = (t < H) ? *trj_at(cur_par, XS + t * M + j, cs) : 0.0;
+  };
+  // cost of node t at (x,u) with the node's goal and multipliers read from its record
+  auto node_cost = [&](int t, const double* x, const double* u) -> double {
+    const double* r = rec(t);
+    double g[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) g[i] = r[(size_t)(RL::rg + i) * ES];
+    if (LEGACY) {
+      double lam[CL];
+#pragma unroll
+      for (int i = 0; i < CL; ++i) lam[i] = r[(size_t)(RL::rl + i) * ES];
+      return OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, g, lam, 1, mu);
+    }
+    return OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, g, r + (size_t)RL::rl * ES, ES, mu);
+  };
+
   // total cost of the current trajectory: node costs in parallel, summed in node order (ilqr.py:52-56)
   auto total_cost = [&]() -> double {
-    const size_t cs = gid * G + cur_lane;
     double total = 0.0;
     for (int t0 = 0; t0 <= H; t0 += G) {
       int t = t0 + gl;
       double ct = 0.0;
       if (t <= H) {
         double x[N], u[M];
-#pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = *trj_at(cur_par, t * N + i, cs);
-#pragma unroll
-        for (int j = 0; j < M; ++j) u[j] = (t < H) ? *trj_at(cur_par, XS + t * M + j, cs) : 0.0;
-        ct = OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, goals + (size_t)t * N, lamw + (size_t)t * C * NG, NG, mu);
+        load_node(t, x, u);
+        ct = node_cost(t, x, u);
       }
       for (int g = 0; g < G && t0 + g <= H; ++g) total += gbcast<G>(ct, g);
     }
@@ -596,7 +651,14 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
         drained = true;
       } else {
         p = np;
-        goals = a.goals + ((a.goal_batch > 1) ? (size_t)p * XS : 0);
+        const double* goals = a.goals + ((a.goal_batch > 1) ? (size_t)p * XS : 0);
+        // goals and zero multipliers into the records, lanes in parallel
+        for (int t = gl; t <= H; t += G) {
+          double* r = rec(t);
+#pragma unroll
+          for (int i = 0; i < N; ++i) r[(size_t)(RL::rg + i) * ES] = goals[(size_t)t * N + i];
+          for (int i = 0; i < C; ++i) r[(size_t)(RL::rl + i) * ES] = 0.0;
+        }
         // ---- linearised-LQR initial guess (ilqr.py:11-50): every lane of the group
         //      carries the same recursion; lane 0 stores.
         double P[N][N];
@@ -611,7 +673,7 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
           double gt[N];
 #pragma unroll
           for (int i = 0; i < N; ++i) gt[i] = goals[(size_t)t * N + i];
-          MD::jac(mc, gt, zu, ac, bc);
+          MD::template jac<false>(mc, gt, zu, ac, bc);
           expand_jac<MD>(mc, ac, bc, S, Bm);
           double W[N][N], Tm[N][M], Mx[M][M], Mi[M][M], BtPA[M][N], Kt[M][N];
           mul_VA<MD>(P, S, W);
@@ -636,6 +698,7 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
             }
           }
           inv_small<M>(Mx, Mi);
+          double* rt = rec(t);
 #pragma unroll
           for (int r = 0; r < M; ++r)
 #pragma unroll
@@ -644,7 +707,7 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
 #pragma unroll
               for (int b = 0; b < M; ++b) acc = fma(Mi[r][b], BtPA[b][j], acc);
               Kt[r][j] = acc;
-              if (gl == 0) kk[(size_t)(t * KS + r * N + j) * NG] = acc;
+              if (gl == 0) rt[(size_t)(RL::rK + r * N + j) * ES] = acc;
             }
           // P = I + A'(W - T K)
           double D[N][N];
@@ -685,15 +748,16 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
             }
           }
           for (int t = 0; t < H; ++t) {
+            const double* rt = rec(t);
             double u[M], xn[N];
 #pragma unroll
             for (int r = 0; r < M; ++r) {
               double acc = 0.0;
 #pragma unroll
-              for (int i = 0; i < N; ++i) acc += (-kk[(size_t)(t * KS + r * N + i) * NG]) * (x[i] - goals[(size_t)t * N + i]);
+              for (int i = 0; i < N; ++i) acc += (-rt[(size_t)(RL::rK + r * N + i) * ES]) * (x[i] - goals[(size_t)t * N + i]);
               u[r] = acc;
             }
-            MD::step(mc, x, u, xn);
+            MD::template step<false>(mc, x, u, xn);
             if (gl == 0) {
 #pragma unroll
               for (int r = 0; r < M; ++r) {
@@ -712,7 +776,6 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
             for (int i = 0; i < N; ++i) x[i] = xn[i];
           }
         }
-        for (int e = gl; e < (H + 1) * C; e += G) lamw[(size_t)e * NG] = 0.0;
         mu = 1.0;
         cur_lane = 0; cur_par = 0;
         outer = 0; inner = 0; n_inner = 0; n_trials = 0;
@@ -731,130 +794,227 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
         outer_start = false;
         inner = 0;
       }
-      const size_t cs = gid * G + cur_lane;     // slot of the current trajectory
       const int np_ = 1 - cur_par;              // parity the candidates are written to
       const size_t myslot = gid * G + gl;
 
       PROF_MARK(1)
       // ================= P1: linearise + quadratise, parallel in time =================
       for (int t = gl; t <= H; t += G) {
-        double x[N], u[M];
+        double x[N], u[M], g[N];
+        load_node(t, x, u);
+        double* r = rec(t);
+        double* lr = lrec(t);
 #pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = *trj_at(cur_par, t * N + i, cs);
+        for (int i = 0; i < N; ++i) { r[(size_t)(RL::rx + i) * ES] = x[i]; g[i] = r[(size_t)(RL::rg + i) * ES]; }
 #pragma unroll
-        for (int j = 0; j < M; ++j) u[j] = (t < H) ? *trj_at(cur_par, XS + t * M + j, cs) : 0.0;
-        double* rec = lin + (size_t)t * LL::E * NG;
+        for (int j = 0; j < M; ++j) r[(size_t)(RL::ru + j) * ES] = u[j];
         if (t < H) {
           double ac[MD::NA], bc[MD::NB];
-          MD::jac(mc, x, u, ac, bc);
+          MD::template jac<true>(mc, x, u, ac, bc);
 #pragma unroll
-          for (int i = 0; i < MD::NA; ++i) rec[(size_t)(LL::oA + i) * NG] = ac[i];
+          for (int i = 0; i < MD::NA; ++i) lr[(size_t)(NR::oA + i) * ES] = ac[i];
 #pragma unroll
-          for (int i = 0; i < MD::NB; ++i) rec[(size_t)(LL::oB + i) * NG] = bc[i];
+          for (int i = 0; i < MD::NB; ++i) lr[(size_t)(NR::oB + i) * ES] = bc[i];
         }
-        OPS::quadratize(a, tabQ(t), tabR(t), tabC(t), x, u, goals + (size_t)t * N,
-                        lamw + (size_t)t * C * NG, NG, mu, rec, NG);
+        double q[LL::E];
+        if (LEGACY) {
+          double lam[CL];
+#pragma unroll
+          for (int i = 0; i < CL; ++i) lam[i] = r[(size_t)(RL::rl + i) * ES];
+          OPS::quadratize(a, tabQ(t), tabR(t), tabC(t), x, u, g, lam, 1, mu, q, 1);
+          // l_xx = 2Q + diag, l_uu = 2R + diag: keep the AL part of the diagonal only (2Q, 2R are uniform tables)
+          const double* Q = tabQ(t);
+          const double* R = tabR(t);
+#pragma unroll
+          for (int i = 0; i < N; ++i) lr[(size_t)(NR::oHx + i) * ES] = q[LL::oLxx + i * N + i];
+#pragma unroll
+          for (int i = 0; i < M; ++i) lr[(size_t)(NR::oHu + i) * ES] = q[LL::oLuu + i * M + i];
+          (void)Q; (void)R;
+        } else {
+          OPS::quadratize(a, tabQ(t), tabR(t), tabC(t), x, u, g, r + (size_t)RL::rl * ES, ES, mu, q, 1);
+#pragma unroll
+          for (int i = 0; i < N * N; ++i) lr[(size_t)(NR::oHx + i) * ES] = q[LL::oLxx + i];
+#pragma unroll
+          for (int i = 0; i < M * M; ++i) lr[(size_t)(NR::oHu + i) * ES] = q[LL::oLuu + i];
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) lr[(size_t)(NR::oLx + i) * ES] = q[LL::oLx + i];
+#pragma unroll
+        for (int i = 0; i < M; ++i) lr[(size_t)(NR::oLu + i) * ES] = q[LL::oLu + i];
       }
       __threadfence_block();
 
       PROF_MARK(2)
       // ================= P2: backward Riccati sweep =================
       {
+        struct LinRegs { double v[NR::E]; };
+        auto load_lin = [&](int t, LinRegs& L) {
+          const double* lr = lrec(t);
+#pragma unroll
+          for (int i = 0; i < NR::E; ++i) L.v[i] = lr[(size_t)i * ES];
+        };
         double Vx[N], Vxx[N][N];
-        const double* recH = lin + (size_t)H * LL::E * NG;
+        {
+          LinRegs LH;
+          load_lin(H, LH);
+          const double* Q = tabQ(H);
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-          Vx[i] = recH[(size_t)(LL::oLx + i) * NG];
+          for (int i = 0; i < N; ++i) {
+            Vx[i] = LH.v[NR::oLx + i];
 #pragma unroll
-          for (int j = 0; j < N; ++j) Vxx[i][j] = recH[(size_t)(LL::oLxx + i * N + j) * NG];
+            for (int j = 0; j < N; ++j)
+              Vxx[i][j] = LEGACY ? ((i == j) ? LH.v[NR::oHx + i] : 2 * Q[i * N + j]) : LH.v[NR::oHx + i * N + j];
+          }
         }
-        for (int t = H - 1; t >= 0; --t) {
-          const double* rec = lin + (size_t)t * LL::E * NG;
-          double ac[MD::NA], bc[MD::NB], S[N][N], Bm[N][M], K[M][N], kf[M];
-#pragma unroll
-          for (int i = 0; i < MD::NA; ++i) ac[i] = rec[(size_t)(LL::oA + i) * NG];
-#pragma unroll
-          for (int i = 0; i < MD::NB; ++i) bc[i] = rec[(size_t)(LL::oB + i) * NG];
-          expand_jac<MD>(mc, ac, bc, S, Bm);
-          riccati_step<MD>(S, Bm, rec + (size_t)LL::oLx * NG, rec + (size_t)LL::oLu * NG,
-                           rec + (size_t)LL::oLxx * NG, rec + (size_t)LL::oLuu * NG, NG, a.prm.quu_reg,
-                           Vx, Vxx, K, kf);
+        auto sweep = [&](int t, const LinRegs& L, LinRegs& Lnext) {
+          if (t > 0) load_lin(t - 1, Lnext);            // in flight while this step computes
+          double S[N][N], Bm[N][M], K[M][N], kf[M];
+          expand_jac<MD>(mc, &L.v[NR::oA], &L.v[NR::oB], S, Bm);
+          const double* Q = tabQ(t);
+          const double* R = tabR(t);
+          riccati_step<MD>(S, Bm,
+                           [&](int i) { return L.v[NR::oLx + i]; },
+                           [&](int r) { return L.v[NR::oLu + r]; },
+                           [&](int i, int j) { return LEGACY ? ((i == j) ? L.v[NR::oHx + i] : 2 * Q[i * N + j]) : L.v[NR::oHx + i * N + j]; },
+                           [&](int r, int b) { return LEGACY ? ((r == b) ? L.v[NR::oHu + r] : 2 * R[r * M + b]) : L.v[NR::oHu + r * M + b]; },
+                           a.prm.quu_reg, Vx, Vxx, K, kf);
           if (gl == 0) {
+            double* rt = rec(t);
 #pragma unroll
             for (int r = 0; r < M; ++r) {
 #pragma unroll
-              for (int j = 0; j < N; ++j) kk[(size_t)(t * KS + r * N + j) * NG] = K[r][j];
-              kk[(size_t)(t * KS + M * N + r) * NG] = kf[r];
+              for (int j = 0; j < N; ++j) rt[(size_t)(RL::rK + r * N + j) * ES] = K[r][j];
+              rt[(size_t)(RL::rk + r) * ES] = kf[r];
             }
           }
+        };
+        LinRegs LA, LB;
+        load_lin(H - 1, LA);
+        int t = H - 1;
+        for (; t >= 1; t -= 2) {
+          sweep(t, LA, LB);
+          sweep(t - 1, LB, LA);
         }
+        if (t == 0) sweep(0, LA, LB);
       }
       __threadfence_block();
 
       PROF_MARK(3)
       // ================= P3: roll-outs, one line-search trial per lane =================
+      struct RecRegs { double x[N], u[M], K[M][N], k[M], g[N], lam[CL]; };
+      auto load_rec = [&](int t, RecRegs& R) {
+        const double* r = rec(t);
+#pragma unroll
+        for (int i = 0; i < N; ++i) { R.x[i] = r[(size_t)(RL::rx + i) * ES]; R.g[i] = r[(size_t)(RL::rg + i) * ES]; }
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          R.u[j] = r[(size_t)(RL::ru + j) * ES];
+          R.k[j] = r[(size_t)(RL::rk + j) * ES];
+#pragma unroll
+          for (int i = 0; i < N; ++i) R.K[j][i] = r[(size_t)(RL::rK + j * N + i) * ES];
+        }
+        if (LEGACY) {
+#pragma unroll
+          for (int i = 0; i < CL; ++i) R.lam[i] = r[(size_t)(RL::rl + i) * ES];
+        }
+      };
       double new_cost = old_cost;
       int win_lane = -1;
-      int rounds = 0;
-      for (int r0 = 0; r0 < ntrials && win_lane < 0; r0 += G, ++rounds) {
+      for (int r0 = 0; r0 < ntrials && win_lane < 0; r0 += G) {
         const int j = r0 + gl + 1;              // trial number, 1-based
         const bool valid = j <= ntrials;
         // alpha_j = 2^-(j-1) (exact halvings, ilqr.py:136)
         double alpha = 1.0;
         for (int q = 1; q < j && q < 64; ++q) alpha = alpha / 2.0;
         const bool closed = (!LEGACY) || (j == 1);    // LEGACY trials >= 2 run open loop on accumulated controls
-        // LEGACY open-loop trials: u_j = (...((base + a_s k) + a_{s+1} k)...) + a_j k
-        const bool from_cur = (r0 == 0) || (r0 == G && gl == 0);
-        const int jstart = (r0 == 0) ? 2 : (j - G + 1);
+        if (LEGACY) {
+          // Accumulated controls of the open-loop trials of this round, nodes in parallel:
+          //   u_i = u_{i-1} + 2^-(i-1) k   (ilqr.py:119 with new_u aliasing u), written to the trial's slot.
+          const int first = (r0 == 0) ? 2 : r0 + 1;
+          const int last = (r0 + G < ntrials) ? r0 + G : ntrials;
+          const bool from_cur = (r0 == 0) || (G == 1 && r0 == 1);
+          for (int t = gl; t < H && first <= last; t += G) {
+            const double* rt = rec(t);
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+              const double kf = rt[(size_t)(RL::rk + r) * ES];
+              double s = from_cur ? rt[(size_t)(RL::ru + r) * ES] : *trj_at(np_, XS + t * M + r, gid * G + (G - 1));
+              double al = 1.0;
+              for (int q = 1; q < first; ++q) al = al / 2.0;
+              for (int i = first; i <= last; ++i) {
+                s = s + al * kf;
+                al = al / 2.0;
+                *trj_at(np_, XS + t * M + r, gid * G + (i - 1 - r0)) = s;
+              }
+            }
+          }
+          __threadfence_block();
+        }
         double J = 0.0;
         double x[N];
+        RecRegs RA, RB;
+        load_rec(0, RA);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-          x[i] = *trj_at(cur_par, i, cs);
+          x[i] = RA.x[i];
           if (valid) *trj_at(np_, i, myslot) = x[i];
         }
-        for (int t = 0; t < H; ++t) {
-          double xo[N], uo[M], u[M], kf[M];
+        double uown[M];
 #pragma unroll
-          for (int i = 0; i < N; ++i) xo[i] = *trj_at(cur_par, t * N + i, cs);
+        for (int r = 0; r < M; ++r) uown[r] = (!closed) ? *trj_at(np_, XS + r, myslot) : 0.0;
+        auto roll = [&](int t, const RecRegs& R, RecRegs& Rn) {
+          load_rec(t + 1, Rn);                         // next record in flight while this step computes
+          double unext[M];
 #pragma unroll
-          for (int r = 0; r < M; ++r) {
-            uo[r] = *trj_at(cur_par, XS + t * M + r, cs);
-            kf[r] = kk[(size_t)(t * KS + M * N + r) * NG];
-          }
+          for (int r = 0; r < M; ++r) unext[r] = (!closed && t + 1 < H) ? *trj_at(np_, XS + (t + 1) * M + r, myslot) : 0.0;
+          double u[M];
           if (closed) {
 #pragma unroll
             for (int r = 0; r < M; ++r) {
               double fb = 0.0;
 #pragma unroll
-              for (int i = 0; i < N; ++i) fb += kk[(size_t)(t * KS + r * N + i) * NG] * (x[i] - xo[i]);
-              u[r] = (uo[r] + alpha * kf[r]) + fb;
+              for (int i = 0; i < N; ++i) fb += R.K[r][i] * (x[i] - R.x[i]);
+              u[r] = (R.u[r] + alpha * R.k[r]) + fb;
             }
           } else {
 #pragma unroll
-            for (int r = 0; r < M; ++r) {
-              double base = from_cur ? uo[r] : *trj_at(np_, XS + t * M + r, myslot);
-              double al = 1.0;
-              for (int q = 1; q < jstart && q < 64; ++q) al = al / 2.0;   // alpha_{jstart}
-              for (int q = jstart; q <= j; ++q) { base = base + al * kf[r]; al = al / 2.0; }
-              u[r] = base;
-            }
+            for (int r = 0; r < M; ++r) u[r] = uown[r];
           }
           if (valid) {
-            J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, goals + (size_t)t * N, lamw + (size_t)t * C * NG, NG, mu);
+            if (LEGACY) J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, R.lam, 1, mu);
+            else J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, rec(t) + (size_t)RL::rl * ES, ES, mu);
             double xn[N];
-            MD::step(mc, x, u, xn);
+            MD::template step<true>(mc, x, u, xn);
+            if (closed) {
 #pragma unroll
-            for (int r = 0; r < M; ++r) *trj_at(np_, XS + t * M + r, myslot) = u[r];
+              for (int r = 0; r < M; ++r) *trj_at(np_, XS + t * M + r, myslot) = u[r];
+            }
 #pragma unroll
             for (int i = 0; i < N; ++i) { x[i] = xn[i]; *trj_at(np_, (t + 1) * N + i, myslot) = xn[i]; }
+          }
+#pragma unroll
+          for (int r = 0; r < M; ++r) uown[r] = unext[r];
+        };
+        int t = 0;
+        for (; t + 1 < H; t += 2) {
+          roll(t, RA, RB);
+          roll(t + 1, RB, RA);
+        }
+        if (t < H) {
+          roll(t, RA, RB);
+#pragma unroll
+          for (int i = 0; i < N; ++i) RA.g[i] = RB.g[i];
+          if (LEGACY) {
+#pragma unroll
+            for (int i = 0; i < CL; ++i) RA.lam[i] = RB.lam[i];
           }
         }
         if (valid) {
           double zu[M];
 #pragma unroll
           for (int r = 0; r < M; ++r) zu[r] = 0.0;
-          J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, goals + (size_t)H * N, lamw + (size_t)H * C * NG, NG, mu);
+          if (LEGACY) J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, RA.lam, 1, mu);
+          else J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, rec(H) + (size_t)RL::rl * ES, ES, mu);
         }
         const bool ok = valid && (J < old_cost);
         int w = gfirst<G>(ok, lane);
@@ -889,7 +1049,6 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
       bool finished = false;
       unsigned flags = 0;
       if (brk || inner >= a.prm.max_inner) {
-        const size_t ns = gid * G + cur_lane;
         // constraint violation of the node trajectory, nodes in parallel, combined in node order
         double vtot = OPS::violation_init();
         for (int t0 = 0; t0 <= H; t0 += G) {
@@ -897,11 +1056,15 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
           double vt = 0.0;
           if (t <= H) {
             double x[N], u[M];
+            load_node(t, x, u);
+            if (LEGACY) {
+              double lam[CL];
 #pragma unroll
-            for (int i = 0; i < N; ++i) x[i] = *trj_at(cur_par, t * N + i, ns);
-#pragma unroll
-            for (int j = 0; j < M; ++j) u[j] = (t < H) ? *trj_at(cur_par, XS + t * M + j, ns) : 0.0;
-            vt = OPS::violation(a, tabC(t), x, u, lamw + (size_t)t * C * NG, NG, mu);
+              for (int i = 0; i < CL; ++i) lam[i] = rec(t)[(size_t)(RL::rl + i) * ES];
+              vt = OPS::violation(a, tabC(t), x, u, lam, 1, mu);
+            } else {
+              vt = OPS::violation(a, tabC(t), x, u, rec(t) + (size_t)RL::rl * ES, ES, mu);
+            }
           }
           for (int g = 0; g < G && t0 + g <= H; ++g) vtot = OPS::combine_violation(vtot, gbcast<G>(vt, g));
         }
@@ -913,11 +1076,8 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
           if (viol >= a.prm.viol_stop && viol < a.prm.viol_lambda) {
             for (int t = gl; t <= H; t += G) {
               double x[N], u[M];
-#pragma unroll
-              for (int i = 0; i < N; ++i) x[i] = *trj_at(cur_par, t * N + i, ns);
-#pragma unroll
-              for (int j = 0; j < M; ++j) u[j] = (t < H) ? *trj_at(cur_par, XS + t * M + j, ns) : 0.0;
-              OPS::update_lambda(a, tabC(t), x, u, lamw + (size_t)t * C * NG, NG, mu);
+              load_node(t, x, u);
+              OPS::update_lambda(a, tabC(t), x, u, rec(t) + (size_t)RL::rl * ES, ES, mu);
             }
             __threadfence_block();
           } else {
@@ -932,7 +1092,9 @@ __global__ __launch_bounds__(64) void solve_kernel(KArgs a) {
         double fc = total_cost();
         if (a.node_x) for (int e = gl; e < XS; e += G) a.node_x[(size_t)p * XS + e] = *trj_at(cur_par, e, ns);
         if (a.node_u) for (int e = gl; e < US; e += G) a.node_u[(size_t)p * US + e] = *trj_at(cur_par, XS + e, ns);
-        if (a.lam) for (int e = gl; e < (H + 1) * C; e += G) a.lam[(size_t)p * (H + 1) * C + e] = lamw[(size_t)e * NG];
+        if (a.lam)
+          for (int e = gl; e < (H + 1) * C; e += G)
+            a.lam[(size_t)p * (H + 1) * C + e] = rec(e / C)[(size_t)(RL::rl + e % C) * ES];
         if (gl == 0) {
           a.cost[p] = fc;
           if (a.viol) a.viol[p] = viol;
