@@ -82,7 +82,7 @@ int32_t check_problem(const alilqr_problem* p, Dims* d) {
 int pick_group(const alilqr_problem* p) {
   if (const char* e = std::getenv("ALILQR_LANES")) {
     int g = std::atoi(e);
-    if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32) return g;
+    if (g == 1 || g == 4 || g == 8 || g == 16 || g == 32) return g;
   }
   const long target_waves = 2048;   // 2 waves on each of the 1024 SIMDs
   for (int g : {32, 8}) {
@@ -132,7 +132,6 @@ int32_t launch_g(const alilqr::KArgs& ka, int G, int waves, hipStream_t st) {
   dim3 grid(waves), block(64);
   switch (G) {
     case 1: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 1>), grid, block, 0, st, ka); break;
-    case 2: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 2>), grid, block, 0, st, ka); break;
     case 4: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 4>), grid, block, 0, st, ka); break;
     case 8: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 8>), grid, block, 0, st, ka); break;
     case 16: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 16>), grid, block, 0, st, ka); break;
@@ -168,6 +167,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(LArgs a) {
   const int cw = (MODE == ALILQR_MODE_LEGACY) ? (2 * N + 2 * M) : a.C * (N + M + 1);
   KArgs ka{};
   ka.C = a.C;
+  ka.qdiag = 0;
   double x[N], u[M], xn[N], ac[MD::NA], bc[MD::NB], S[N][N], Bm[N][M];
 #pragma unroll
   for (int q = 0; q < N; ++q) x[q] = a.x[i * N + q];
@@ -180,9 +180,9 @@ __global__ __launch_bounds__(256) void linearize_kernel(LArgs a) {
   x[2] = wrap_py(x[2]);
   x[3] = wrap_py(x[3]);
   const double* g = a.goals + ((a.goal_batch > 1) ? (size_t)b * (a.H + 1) * N : 0) + (size_t)t * N;
-  const double* Q = a.Q + (size_t)tt * N * N;
-  const double* R = a.R + (size_t)tt * M * M;
-  const double* tab = a.cons + (size_t)tt * cw;
+  ctab Q = as_ctab(a.Q) + (size_t)tt * N * N;
+  ctab R = as_ctab(a.R) + (size_t)tt * M * M;
+  ctab tab = as_ctab(a.cons) + (size_t)tt * cw;
   const double* lam = a.lam + i * a.C;
   const double mu = a.mu[b];
   double rec[LL::E];

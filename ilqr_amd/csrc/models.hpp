@@ -7,7 +7,7 @@
 //
 // The arithmetic of step()/jac() keeps the operation order of the Python node
 // files (no FMA contraction: the translation unit is built with
-// -ffp-contract=off); only sin/cos/tan come from the device math library.
+// -ffp-contract=off); sin/cos/tan are the range-limited kernels of trig.hpp.
 //
 // Reference formulas:
 //   LAT      cilqr/lat_bicycle_node.py:32-91
@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/alilqr.h"
+#include "trig.hpp"
 
 namespace alilqr {
 
@@ -76,16 +77,17 @@ struct Model<ALILQR_MODEL_LAT> : Lat4Base {
     const double v = mc.v, dt = mc.dt, L = mc.L;
     double th = wrap_in<WRAPPED>(x[2]), de = wrap_in<WRAPPED>(x[3]);
     double s1, c1;
-    sincos(th, &s1, &c1);
-    double k1[4] = {v * c1, v * s1, v * tan(de) / L, u[0]};
+    sincos_w(th, &s1, &c1);
+    const bool unitL = (L == 1.0);      // x / 1.0 == x: skip the division
+    double k1[4] = {v * c1, v * s1, unitL ? v * tan_w(de) : v * tan_w(de) / L, u[0]};
     double hdt = 0.5 * dt;
     double mid[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) mid[i] = x[i] + hdt * k1[i];
     double thm = wrap_py(mid[2]), dem = wrap_py(mid[3]);
     double s2, c2;
-    sincos(thm, &s2, &c2);
-    double k2[4] = {v * c2, v * s2, v * tan(dem) / L, u[0]};
+    sincos_w(thm, &s2, &c2);
+    double k2[4] = {v * c2, v * s2, unitL ? v * tan_w(dem) : v * tan_w(dem) / L, u[0]};
 #pragma unroll
     for (int i = 0; i < 4; ++i) xn[i] = x[i] + dt * k2[i];
     xn[2] = wrap_py(xn[2]);
@@ -96,11 +98,11 @@ struct Model<ALILQR_MODEL_LAT> : Lat4Base {
     const double v = mc.v, dt = mc.dt, L = mc.L;
     double th = wrap_in<WRAPPED>(x[2]), de = wrap_in<WRAPPED>(x[3]);
     double u = uc[0];
-    double td = tan(de);
+    double td = tan_w(de);
     double tm = th + 0.5 * dt * v * td / L;
-    double tu = tan(de + 0.5 * dt * u);
+    double tu = tan_w(de + 0.5 * dt * u);
     double sm, cm;
-    sincos(tm, &sm, &cm);
+    sincos_w(tm, &sm, &cm);
     double dt2 = dt * dt, v2 = v * v;
     a[0] = -dt * v * sm;
     a[1] = -0.5 * dt2 * v2 * (td * td + 1) * sm / L;
@@ -134,13 +136,13 @@ struct Full6 : Full6Base {
     double th = wrap_in<WRAPPED>(s[2]), de = wrap_in<WRAPPED>(s[3]);
     double v = s[4], acc = s[5];
     double sn, cs;
-    sincos(th, &sn, &cs);
+    sincos_w(th, &sn, &cs);
     out[0] = v * cs;
     out[1] = v * sn;
     if (MODEL == ALILQR_MODEL_KIN)
-      out[2] = v * tan(de) / mc.L;
+      out[2] = v * tan_w(de) / mc.L;
     else
-      out[2] = v * tan(de) / (mc.L * (1 + mc.k * (v * v)));
+      out[2] = v * tan_w(de) / (mc.L * (1 + mc.k * (v * v)));
     out[3] = u[0];
     out[4] = acc;
     out[5] = u[1];
@@ -164,13 +166,13 @@ struct Full6 : Full6Base {
     double theta = wrap_in<WRAPPED>(x[2]), delta = wrap_in<WRAPPED>(x[3]);
     double v = x[4], acc = x[5], u1 = uc[0];
     double dt2 = dt * dt;
-    double tan_delta = tan(delta);
-    double tan_u1 = tan(delta + 0.5 * dt * u1);
+    double tan_delta = tan_w(delta);
+    double tan_u1 = tan_w(delta + 0.5 * dt * u1);
     double vt = 0.5 * acc * dt + v;
     if (MODEL == ALILQR_MODEL_KIN) {
       double theta_mid = theta + 0.5 * dt * v * tan_delta / L;
       double sn, c;
-      sincos(theta_mid, &sn, &c);
+      sincos_w(theta_mid, &sn, &c);
       double tds = tan_delta * tan_delta, tus = tan_u1 * tan_u1;
       double v_tu = v * (tus + 1);
       a[0] = -dt * vt * sn;
@@ -189,7 +191,7 @@ struct Full6 : Full6Base {
       double sf = 1 + k * (v * v);
       double theta_mid = theta + 0.5 * dt * v * tan_delta / (L * sf);
       double sn, c;
-      sincos(theta_mid, &sn, &c);
+      sincos_w(theta_mid, &sn, &c);
       double tds = tan_delta * tan_delta, tus = tan_u1 * tan_u1;
       double v_tu = v * (tus + 1);
       double g = -dt * k * (v * v) * tan_delta / (L * (sf * sf)) + 0.5 * dt * tan_delta / (L * sf);
@@ -212,7 +214,7 @@ struct Full6 : Full6Base {
       double denom_mid = L * (k_vm_sq + 1);
       double theta_mid = theta + 0.5 * dt * v * tan_delta / denom;
       double sn, c;
-      sincos(theta_mid, &sn, &c);
+      sincos_w(theta_mid, &sn, &c);
       double g = -dt * k_v_sq * tan_delta / (denom * denom) + 0.5 * dt * tan_delta / denom;
       double tms = tan_u1 * tan_u1;
       a[0] = -dt * vt * sn;

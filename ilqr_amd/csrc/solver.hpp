@@ -48,8 +48,19 @@ namespace alilqr {
 #define PROF_FLUSH(a)
 #endif
 
+// Read-only tables (Q, R, constraint tables) are addressed through the constant address space so that
+// their uniform reads become scalar loads held in SGPRs instead of per-lane vector loads.
+typedef const double __attribute__((address_space(4)))* ctab;
+__device__ __forceinline__ ctab as_ctab(const double* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (ctab)p;
+#pragma clang diagnostic pop
+}
+
 struct KArgs {
   int B, NG, H, C, goal_batch, table_nodes;
+  int qdiag;                  // every Q table is diagonal (set in the kernel prologue)
   ModelConst mc;
   alilqr_params prm;
   const double *x0, *goals, *Q, *R, *cons;
@@ -285,7 +296,7 @@ __device__ __forceinline__ void riccati_step(const double (&S)[MD::N][MD::N], co
 // `lam` points at this node's first multiplier in the workspace (stride NG).
 // ---------------------------------------------------------------------------
 template <int N>
-__device__ __forceinline__ double quad_form(const double* e, const double* Q) {  // e' Q e, reference order
+__device__ __forceinline__ double quad_form(const double* e, ctab Q) {  // e' Q e, reference order
   double s = 0.0;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -294,6 +305,15 @@ __device__ __forceinline__ double quad_form(const double* e, const double* Q) { 
     for (int i = 0; i < N; ++i) t += e[i] * Q[i * N + j];
     s += t * e[j];
   }
+  return s;
+}
+
+// e' Q e for a diagonal Q: the off-diagonal products of the dense form are exact zeros, so this is the same sum
+template <int N>
+__device__ __forceinline__ double quad_form_diag(const double* e, ctab Q) {
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) s += (e[j] * Q[j * N + j]) * e[j];
   return s;
 }
 
@@ -308,36 +328,52 @@ struct NodeOps<MODEL, ALILQR_MODE_LEGACY> {
   static constexpr int N = MD::N, M = MD::M, C = 2 * (N + M);
 
   // constraint i of (x,u): [x - smax ; smin - x ; u - cmax ; cmin - u]
-  __device__ static __forceinline__ double cval(const double* box, const double* x, const double* u, int i) {
-    const double *smin = box, *smax = box + N, *cmin = box + 2 * N, *cmax = box + 2 * N + M;
+  __device__ static __forceinline__ double cval(ctab box, const double* x, const double* u, int i) {
+    ctab smin = box, smax = box + N, cmin = box + 2 * N, cmax = box + 2 * N + M;
     if (i < N) return x[i] - smax[i];
     if (i < 2 * N) return smin[i - N] - x[i - N];
     if (i < 2 * N + M) return u[i - 2 * N] - cmax[i - 2 * N];
     return cmin[i - 2 * N - M] - u[i - 2 * N - M];
   }
-  __device__ static double cost(const KArgs& a, const double* Q, const double* R, const double* box,
+  __device__ static double cost(const KArgs& a, ctab Q, ctab R, ctab box,
                                 const double* x, const double* u, const double* g,
                                 const double* lam, size_t ls, double mu) {
     double e[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) e[i] = x[i] - g[i];
-    double sc = quad_form<N>(e, Q);
+    double sc = a.qdiag ? quad_form_diag<N>(e, Q) : quad_form<N>(e, Q);
     double cc = quad_form<M>(u, R);
     double lc = 0.0, qc = 0.0;
     const double half = (MODEL == ALILQR_MODEL_DYN) ? 0.5 : 0.5 * mu;
+    // A row with lam == 0 and c <= 0 adds exact zeros to both sums.  The 2N state rows are tested with
+    // compares only (x <= x_max, x >= x_min, lam == 0); when no lane of the wave has an active state row
+    // the whole block is skipped — same bits, far fewer instructions on loosely bounded states.
+    bool state_active = false;
 #pragma unroll
-    for (int i = 0; i < C; ++i) {
+    for (int i = 0; i < N; ++i)
+      state_active |= !(x[i] <= box[N + i]) | !(x[i] >= box[i]) | (lam[i * ls] != 0.0) | (lam[(N + i) * ls] != 0.0);
+    if (__any(state_active)) {
+#pragma unroll
+      for (int i = 0; i < 2 * N; ++i) {
+        double c = cval(box, x, u, i);
+        double l = lam[i * ls];
+        double im = (l == 0.0 && c <= 0.0) ? 0.0 : mu;
+        lc += l * c;
+        qc += ((half * c) * im) * c;
+      }
+    }
+#pragma unroll
+    for (int i = 2 * N; i < C; ++i) {
       double c = cval(box, x, u, i);
       double l = lam[i * ls];
       double im = (l == 0.0 && c <= 0.0) ? 0.0 : mu;
       lc += l * c;
       qc += ((half * c) * im) * c;
     }
-    (void)a;
     return sc + cc + (lc + qc);
   }
   // l_x, l_u, l_xx, l_uu written straight into the node's `lin` record
-  __device__ static void quadratize(const KArgs& a, const double* Q, const double* R, const double* box,
+  __device__ static void quadratize(const KArgs& a, ctab Q, ctab R, ctab box,
                                     const double* x, const double* u, const double* g,
                                     const double* lam, size_t ls, double mu,
                                     double* rec, size_t rs) {
@@ -376,7 +412,7 @@ struct NodeOps<MODEL, ALILQR_MODE_LEGACY> {
     (void)a;
   }
   // per-node term of the violation measure: || max(-lam/mu, c) ||_2  (cilqr/ilqr.py:186-192)
-  __device__ static double violation(const KArgs& a, const double* box, const double* x, const double* u,
+  __device__ static double violation(const KArgs& a, ctab box, const double* x, const double* u,
                                      const double* lam, size_t ls, double mu) {
     double ss = 0.0;
 #pragma unroll
@@ -391,7 +427,7 @@ struct NodeOps<MODEL, ALILQR_MODE_LEGACY> {
   __device__ static double combine_violation(double acc, double node) { return acc + node; }
   __device__ static double violation_init() { return 0.0; }
   // lam <- max(0, lam + mu c)   (cilqr/lat_bicycle_node.py:162-165)
-  __device__ static void update_lambda(const KArgs& a, const double* box, const double* x, const double* u,
+  __device__ static void update_lambda(const KArgs& a, ctab box, const double* x, const double* u,
                                        double* lam, size_t ls, double mu) {
 #pragma unroll
     for (int i = 0; i < C; ++i) {
@@ -409,8 +445,8 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
   using MD = Model<MODEL>;
   static constexpr int N = MD::N, M = MD::M;
 
-  __device__ static __forceinline__ double cval(const KArgs& a, const double* tab, const double* x, const double* u, int i) {
-    const double *A = tab, *Bm = tab + a.C * N, *Cv = tab + a.C * (N + M);
+  __device__ static __forceinline__ double cval(const KArgs& a, ctab tab, const double* x, const double* u, int i) {
+    ctab A = tab, Bm = tab + a.C * N, Cv = tab + a.C * (N + M);
     double ax = 0.0, bu = 0.0;
 #pragma unroll
     for (int j = 0; j < N; ++j) ax += A[i * N + j] * x[j];
@@ -418,13 +454,13 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
     for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
     return (ax + bu) + Cv[i];
   }
-  __device__ static double cost(const KArgs& a, const double* Q, const double* R, const double* tab,
+  __device__ static double cost(const KArgs& a, ctab Q, ctab R, ctab tab,
                                 const double* x, const double* u, const double* g,
                                 const double* lam, size_t ls, double mu) {
     double e[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) e[i] = x[i] - g[i];
-    double sc = quad_form<N>(e, Q);
+    double sc = a.qdiag ? quad_form_diag<N>(e, Q) : quad_form<N>(e, Q);
     double cc = quad_form<M>(u, R);
     double pp = 0.0, ll = 0.0;
     for (int i = 0; i < a.C; ++i) {
@@ -436,12 +472,12 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
     }
     return sc + cc + 0.5 / mu * (pp - ll);
   }
-  __device__ static void quadratize(const KArgs& a, const double* Q, const double* R, const double* tab,
+  __device__ static void quadratize(const KArgs& a, ctab Q, ctab R, ctab tab,
                                     const double* x, const double* u, const double* g,
                                     const double* lam, size_t ls, double mu,
                                     double* rec, size_t rs) {
     using LL = LinLayout<MD>;
-    const double *A = tab, *Bm = tab + a.C * N;
+    ctab A = tab, Bm = tab + a.C * N;
     double e[N], jx[N], ju[M], hx[N][N], hu[M][M];
 #pragma unroll
     for (int i = 0; i < N; ++i) { e[i] = x[i] - g[i]; jx[i] = 0.0; }
@@ -493,7 +529,7 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
     }
   }
   // per-node || c - min(c,0) ||_inf  (cilqr/constraints.py:115-119)
-  __device__ static double violation(const KArgs& a, const double* tab, const double* x, const double* u,
+  __device__ static double violation(const KArgs& a, ctab tab, const double* x, const double* u,
                                      const double* lam, size_t ls, double mu) {
     double v = 0.0;
     for (int i = 0; i < a.C; ++i) {
@@ -508,7 +544,7 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
   __device__ static double combine_violation(double acc, double node) { return (node > acc || node != node) ? node : acc; }
   __device__ static double violation_init() { return -1.0; }
   // lam <- min(lam - mu c, 0)  (cilqr/constraints.py:106-110; c is the value cached by max_violation at the same point)
-  __device__ static void update_lambda(const KArgs& a, const double* tab, const double* x, const double* u,
+  __device__ static void update_lambda(const KArgs& a, ctab tab, const double* x, const double* u,
                                        double* lam, size_t ls, double mu) {
     for (int i = 0; i < a.C; ++i) {
       double c = cval(a, tab, x, u, i);
@@ -579,6 +615,17 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   double* const trj = a.trj;
   const int cw = LEGACY ? (2 * N + 2 * M) : C * (N + M + 1);   // doubles per constraint table
 
+  // is every state-weight table diagonal?  (uniform scalar reads, once per kernel)
+  {
+    bool diag = true;
+    ctab Qt = as_ctab(a.Q);
+    for (int t = 0; t < a.table_nodes; ++t)
+      for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j)
+          if (i != j && Qt[(size_t)t * N * N + i * N + j] != 0.0) diag = false;
+    a.qdiag = diag ? 1 : 0;
+  }
+
   // number of line-search trials the reference can make: alpha = 1, 1/2, ... while alpha > alpha_min
   int ntrials = 0;
   for (double al = 1.0; al > a.prm.alpha_min && ntrials < 64; al = al / 2.0) ++ntrials;
@@ -596,9 +643,9 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   };
   auto rec = [&](int t) -> double* { return blk + (size_t)t * RS * ES; };
   auto lrec = [&](int t) -> double* { return linb + (size_t)t * NR::E * ES; };
-  auto tabQ = [&](int t) { return a.Q + (size_t)((a.table_nodes > 1) ? t : 0) * N * N; };
-  auto tabR = [&](int t) { return a.R + (size_t)((a.table_nodes > 1) ? t : 0) * M * M; };
-  auto tabC = [&](int t) { return a.cons + (size_t)((a.table_nodes > 1) ? t : 0) * cw; };
+  auto tabQ = [&](int t) { return as_ctab(a.Q) + (size_t)((a.table_nodes > 1) ? t : 0) * N * N; };
+  auto tabR = [&](int t) { return as_ctab(a.R) + (size_t)((a.table_nodes > 1) ? t : 0) * M * M; };
+  auto tabC = [&](int t) { return as_ctab(a.cons) + (size_t)((a.table_nodes > 1) ? t : 0) * cw; };
 
   // node t of the current trajectory (slot of the last accepted roll-out)
   auto load_node = [&](int t, double* x, double* u) {
@@ -823,8 +870,8 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
           for (int i = 0; i < CL; ++i) lam[i] = r[(size_t)(RL::rl + i) * ES];
           OPS::quadratize(a, tabQ(t), tabR(t), tabC(t), x, u, g, lam, 1, mu, q, 1);
           // l_xx = 2Q + diag, l_uu = 2R + diag: keep the AL part of the diagonal only (2Q, 2R are uniform tables)
-          const double* Q = tabQ(t);
-          const double* R = tabR(t);
+          ctab Q = tabQ(t);
+          ctab R = tabR(t);
 #pragma unroll
           for (int i = 0; i < N; ++i) lr[(size_t)(NR::oHx + i) * ES] = q[LL::oLxx + i * N + i];
 #pragma unroll
@@ -857,7 +904,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         {
           LinRegs LH;
           load_lin(H, LH);
-          const double* Q = tabQ(H);
+          ctab Q = tabQ(H);
 #pragma unroll
           for (int i = 0; i < N; ++i) {
             Vx[i] = LH.v[NR::oLx + i];
@@ -870,8 +917,8 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
           if (t > 0) load_lin(t - 1, Lnext);            // in flight while this step computes
           double S[N][N], Bm[N][M], K[M][N], kf[M];
           expand_jac<MD>(mc, &L.v[NR::oA], &L.v[NR::oB], S, Bm);
-          const double* Q = tabQ(t);
-          const double* R = tabR(t);
+          ctab Q = tabQ(t);
+          ctab R = tabR(t);
           riccati_step<MD>(S, Bm,
                            [&](int i) { return L.v[NR::oLx + i]; },
                            [&](int r) { return L.v[NR::oLu + r]; },
