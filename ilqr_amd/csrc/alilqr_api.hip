@@ -93,7 +93,7 @@ int pick_group(const alilqr_problem* p) {
 
 struct Plan {
   int G, NG;
-  size_t trj, blk, counter, total;   // byte offsets / total
+  size_t trj, blk, ucum, counter, total;   // byte offsets / total
 };
 
 size_t block_doubles_for(const alilqr_problem* p) {
@@ -121,7 +121,9 @@ Plan make_plan(const alilqr_problem* p, const Dims& d) {
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   size_t off = 0;
   pl.counter = off; off = up(off + 256);
-  pl.trj = off; off = up(off + sizeof(double) * 2 * T * (size_t)pl.NG * pl.G);
+  const size_t SS = (p->mode == ALILQR_MODE_LEGACY) ? alilqr::TrjSlots<ALILQR_MODE_LEGACY>::SS : alilqr::TrjSlots<ALILQR_MODE_FAST>::SS;
+  pl.trj = off; off = up(off + sizeof(double) * 2 * T * (size_t)pl.NG * SS);
+  pl.ucum = off; off = up(off + sizeof(double) * H * M * (size_t)pl.NG * pl.G);
   pl.blk = off; off = up(off + sizeof(double) * block_doubles_for(p) * (size_t)pl.NG);
   pl.total = off;
   return pl;
@@ -295,7 +297,7 @@ int32_t alilqr_solve_batch(const alilqr_problem* p,
   ka.x_out = x_out; ka.u_out = u_out; ka.node_x = node_x; ka.node_u = node_u;
   ka.x_init = x_init; ka.u_init = u_init; ka.cost = cost; ka.viol = viol; ka.lam = lam; ka.mu = mu;
   ka.status = status;
-  ka.trj = (double*)(base + pl.trj); ka.blk = (double*)(base + pl.blk);
+  ka.trj = (double*)(base + pl.trj); ka.blk = (double*)(base + pl.blk); ka.ucum = (double*)(base + pl.ucum);
   ka.counter = (unsigned int*)(base + pl.counter);
   ka.prof = (unsigned long long*)(base + pl.counter + 128);   // zeroed with the counter; read by profiling builds
   const int waves = pl.NG * pl.G / 64;

@@ -77,17 +77,17 @@ struct Model<ALILQR_MODEL_LAT> : Lat4Base {
     const double v = mc.v, dt = mc.dt, L = mc.L;
     double th = wrap_in<WRAPPED>(x[2]), de = wrap_in<WRAPPED>(x[3]);
     double s1, c1;
-    sincos_w(th, &s1, &c1);
+    sincos_pi(th, &s1, &c1);
     const bool unitL = (L == 1.0);      // x / 1.0 == x: skip the division
-    double k1[4] = {v * c1, v * s1, unitL ? v * tan_w(de) : v * tan_w(de) / L, u[0]};
+    double k1[4] = {v * c1, v * s1, unitL ? v * tan_pi(de) : v * tan_pi(de) / L, u[0]};
     double hdt = 0.5 * dt;
     double mid[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) mid[i] = x[i] + hdt * k1[i];
     double thm = wrap_py(mid[2]), dem = wrap_py(mid[3]);
     double s2, c2;
-    sincos_w(thm, &s2, &c2);
-    double k2[4] = {v * c2, v * s2, unitL ? v * tan_w(dem) : v * tan_w(dem) / L, u[0]};
+    sincos_pi(thm, &s2, &c2);
+    double k2[4] = {v * c2, v * s2, unitL ? v * tan_pi(dem) : v * tan_pi(dem) / L, u[0]};
 #pragma unroll
     for (int i = 0; i < 4; ++i) xn[i] = x[i] + dt * k2[i];
     xn[2] = wrap_py(xn[2]);
@@ -136,13 +136,13 @@ struct Full6 : Full6Base {
     double th = wrap_in<WRAPPED>(s[2]), de = wrap_in<WRAPPED>(s[3]);
     double v = s[4], acc = s[5];
     double sn, cs;
-    sincos_w(th, &sn, &cs);
+    sincos_pi(th, &sn, &cs);
     out[0] = v * cs;
     out[1] = v * sn;
     if (MODEL == ALILQR_MODEL_KIN)
-      out[2] = v * tan_w(de) / mc.L;
+      out[2] = v * tan_pi(de) / mc.L;
     else
-      out[2] = v * tan_w(de) / (mc.L * (1 + mc.k * (v * v)));
+      out[2] = v * tan_pi(de) / (mc.L * (1 + mc.k * (v * v)));
     out[3] = u[0];
     out[4] = acc;
     out[5] = u[1];

@@ -24,9 +24,10 @@
 //        G > 1: the block is contiguous (problem-major), so a sequential sweep reads one
 //        short run of doubles per step from one base address; G = 1: element-major /
 //        group-minor, so the 64 problems of a wave read one contiguous run per element.
-//   trj  [2][T][NG*G]  candidate trajectories, one slot per lane and parity, lane-minor:
-//        the roll-out stores of a wave are contiguous 512-B runs.
-// The current trajectory of a problem is the pair (slot lane, parity) of the last
+//   trj  [2][T][NG*SS] candidate trajectories: SS slots per problem and parity, kept only for
+//        the trials that usually win; any other winner is rolled out a second time.
+//   ucum [H*M][NG*G]   LEGACY: accumulated controls of the open-loop trials, lane-minor.
+// The current trajectory of a problem is the pair (slot, parity) of the last
 // accepted roll-out; nothing is copied on acceptance.  Sequential sweeps (P2, P3)
 // load the record of the next step before computing the current one.
 //
@@ -66,7 +67,7 @@ struct KArgs {
   const double *x0, *goals, *Q, *R, *cons;
   double *x_out, *u_out, *node_x, *node_u, *x_init, *u_init, *cost, *viol, *lam, *mu;
   int32_t* status;
-  double *trj, *blk;
+  double *trj, *blk, *ucum;
   unsigned int* counter;
   unsigned long long* prof;   // optional phase cycle counters (profiling builds only)
 };
@@ -585,6 +586,10 @@ __host__ __device__ inline size_t block_doubles(int H, int C) {
 #ifndef ALILQR_MINW_N4
 #define ALILQR_MINW_N4 2   // waves per SIMD the 4-state kernels are compiled for (256 registers per lane)
 #endif
+// trajectory slots per problem and parity: the usual winners + one spare for a repeated roll-out
+template <int MODE>
+struct TrjSlots { static constexpr int SS = (MODE == ALILQR_MODE_LEGACY) ? 4 : 8; };
+
 template <int MODEL, int MODE, int G>
 __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) void solve_kernel(KArgs a) {
   using MD = Model<MODEL>;
@@ -596,6 +601,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   constexpr bool LEGACY = (MODE == ALILQR_MODE_LEGACY);
   constexpr bool PM = (G > 1);                         // block layout: problem-major (contiguous) or element-major
   constexpr int CL = LEGACY ? 2 * (N + M) : 1;         // multipliers held in registers (LEGACY only)
+  constexpr int SS = TrjSlots<MODE>::SS;               // trajectory slots kept per problem and parity
 
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);                       // lane inside the group
@@ -633,14 +639,17 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   // ---- per-group state (identical in every lane of a group) ----
   int p = -1;                 // problem being solved, -1: none
   bool drained = false;       // the batch counter ran out
-  int cur_lane = 0, cur_par = 0;
+  int cur_slot = 0, cur_par = 0;
   double mu = 1.0, old_cost = 0.0, viol = 0.0;
   int outer = 0, inner = 0, n_inner = 0, n_trials = 0;
   bool outer_start = false;
 
-  auto trj_at = [&](int par, int off, size_t slot_lane) -> double* {
-    return trj + ((size_t)par * T + off) * LT + slot_lane;
+  // candidate trajectories: [parity][element][group * SS + slot]
+  auto trj_at = [&](int par, int off, int slot) -> double* {
+    return trj + ((size_t)par * T + off) * (NG * SS) + gid * SS + slot;
   };
+  // accumulated controls of the LEGACY open-loop trials: [t * M + r][global lane]
+  auto ucum_at = [&](int off, size_t lane_global) -> double* { return a.ucum + (size_t)off * LT + lane_global; };
   auto rec = [&](int t) -> double* { return blk + (size_t)t * RS * ES; };
   auto lrec = [&](int t) -> double* { return linb + (size_t)t * NR::E * ES; };
   auto tabQ = [&](int t) { return as_ctab(a.Q) + (size_t)((a.table_nodes > 1) ? t : 0) * N * N; };
@@ -649,11 +658,10 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
 
   // node t of the current trajectory (slot of the last accepted roll-out)
   auto load_node = [&](int t, double* x, double* u) {
-    const size_t cs = gid * G + cur_lane;
 #pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = *trj_at(cur_par, t * N + i, cs);
+    for (int i = 0; i < N; ++i) x[i] = *trj_at(cur_par, t * N + i, cur_slot);
 #pragma unroll
-    for (int j = 0; j < M; ++j) u[j] = (t < H) ? *trj_at(cur_par, XS + t * M + j, cs) : 0.0;
+    for (int j = 0; j < M; ++j) u[j] = (t < H) ? *trj_at(cur_par, XS + t * M + j, cur_slot) : 0.0;
   };
   // cost of node t at (x,u) with the node's goal and multipliers read from its record
   auto node_cost = [&](int t, const double* x, const double* u) -> double {
@@ -781,7 +789,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         __threadfence_block();
         // roll-out u = -K (x - goal) from the raw start state; trajectory goes to slot (lane 0, parity 0)
         {
-          const size_t cs = gid * G;
+          const int cs = 0;
           double x[N];
 #pragma unroll
           for (int i = 0; i < N; ++i) x[i] = a.x0[(size_t)p * N + i];
@@ -824,7 +832,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
           }
         }
         mu = 1.0;
-        cur_lane = 0; cur_par = 0;
+        cur_slot = 0; cur_par = 0;
         outer = 0; inner = 0; n_inner = 0; n_trials = 0;
         outer_start = true;
         __threadfence_block();
@@ -842,7 +850,6 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         inner = 0;
       }
       const int np_ = 1 - cur_par;              // parity the candidates are written to
-      const size_t myslot = gid * G + gl;
 
       PROF_MARK(1)
       // ================= P1: linearise + quadratise, parallel in time =================
@@ -965,38 +972,15 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
           for (int i = 0; i < CL; ++i) R.lam[i] = r[(size_t)(RL::rl + i) * ES];
         }
       };
-      double new_cost = old_cost;
-      int win_lane = -1;
-      for (int r0 = 0; r0 < ntrials && win_lane < 0; r0 += G) {
-        const int j = r0 + gl + 1;              // trial number, 1-based
-        const bool valid = j <= ntrials;
-        // alpha_j = 2^-(j-1) (exact halvings, ilqr.py:136)
-        double alpha = 1.0;
-        for (int q = 1; q < j && q < 64; ++q) alpha = alpha / 2.0;
-        const bool closed = (!LEGACY) || (j == 1);    // LEGACY trials >= 2 run open loop on accumulated controls
-        if (LEGACY) {
-          // Accumulated controls of the open-loop trials of this round, nodes in parallel:
-          //   u_i = u_{i-1} + 2^-(i-1) k   (ilqr.py:119 with new_u aliasing u), written to the trial's slot.
-          const int first = (r0 == 0) ? 2 : r0 + 1;
-          const int last = (r0 + G < ntrials) ? r0 + G : ntrials;
-          const bool from_cur = (r0 == 0) || (G == 1 && r0 == 1);
-          for (int t = gl; t < H && first <= last; t += G) {
-            const double* rt = rec(t);
-#pragma unroll
-            for (int r = 0; r < M; ++r) {
-              const double kf = rt[(size_t)(RL::rk + r) * ES];
-              double s = from_cur ? rt[(size_t)(RL::ru + r) * ES] : *trj_at(np_, XS + t * M + r, gid * G + (G - 1));
-              double al = 1.0;
-              for (int q = 1; q < first; ++q) al = al / 2.0;
-              for (int i = first; i <= last; ++i) {
-                s = s + al * kf;
-                al = al / 2.0;
-                *trj_at(np_, XS + t * M + r, gid * G + (i - 1 - r0)) = s;
-              }
-            }
-          }
-          __threadfence_block();
-        }
+      // Only the trials that usually win keep their trajectory (LEGACY: 1, 2 and the last one, which the
+      // reference is left with when every step is rejected; FAST: the first SS-1).  Any other winner is
+      // rolled out once more into the spare slot SS-1: same code, same inputs, same bits.
+      auto store_slot = [&](int j) -> int {
+        if (LEGACY) return (j == 1) ? 0 : (j == 2) ? 1 : (j == ntrials) ? 2 : -1;
+        return (j <= SS - 1) ? j - 1 : -1;
+      };
+      // roll out one trial: closed loop with step alpha, or open loop on the accumulated controls of lane `ul`
+      auto rollout = [&](bool valid, bool closed, double alpha, size_t ul, int sslot) -> double {
         double J = 0.0;
         double x[N];
         RecRegs RA, RB;
@@ -1004,16 +988,16 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
 #pragma unroll
         for (int i = 0; i < N; ++i) {
           x[i] = RA.x[i];
-          if (valid) *trj_at(np_, i, myslot) = x[i];
+          if (valid && sslot >= 0) *trj_at(np_, i, sslot) = x[i];
         }
         double uown[M];
 #pragma unroll
-        for (int r = 0; r < M; ++r) uown[r] = (!closed) ? *trj_at(np_, XS + r, myslot) : 0.0;
+        for (int r = 0; r < M; ++r) uown[r] = (!closed) ? *ucum_at(r, ul) : 0.0;
         auto roll = [&](int t, const RecRegs& R, RecRegs& Rn) {
           load_rec(t + 1, Rn);                         // next record in flight while this step computes
           double unext[M];
 #pragma unroll
-          for (int r = 0; r < M; ++r) unext[r] = (!closed && t + 1 < H) ? *trj_at(np_, XS + (t + 1) * M + r, myslot) : 0.0;
+          for (int r = 0; r < M; ++r) unext[r] = (!closed && t + 1 < H) ? *ucum_at((t + 1) * M + r, ul) : 0.0;
           double u[M];
           if (closed) {
 #pragma unroll
@@ -1032,12 +1016,14 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
             else J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, rec(t) + (size_t)RL::rl * ES, ES, mu);
             double xn[N];
             MD::template step<true>(mc, x, u, xn);
-            if (closed) {
+            if (sslot >= 0) {
 #pragma unroll
-              for (int r = 0; r < M; ++r) *trj_at(np_, XS + t * M + r, myslot) = u[r];
+              for (int r = 0; r < M; ++r) *trj_at(np_, XS + t * M + r, sslot) = u[r];
+#pragma unroll
+              for (int i = 0; i < N; ++i) *trj_at(np_, (t + 1) * N + i, sslot) = xn[i];
             }
 #pragma unroll
-            for (int i = 0; i < N; ++i) { x[i] = xn[i]; *trj_at(np_, (t + 1) * N + i, myslot) = xn[i]; }
+            for (int i = 0; i < N; ++i) x[i] = xn[i];
           }
 #pragma unroll
           for (int r = 0; r < M; ++r) uown[r] = unext[r];
@@ -1063,23 +1049,68 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
           if (LEGACY) J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, RA.lam, 1, mu);
           else J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, rec(H) + (size_t)RL::rl * ES, ES, mu);
         }
+        return J;
+      };
+      auto alpha_of = [&](int j) -> double {     // 2^-(j-1) by exact halvings (ilqr.py:136)
+        double al = 1.0;
+        for (int q = 1; q < j && q < 64; ++q) al = al / 2.0;
+        return al;
+      };
+      double new_cost = old_cost;
+      int win_trial = -1, win_lane = -1;
+      for (int r0 = 0; r0 < ntrials && win_trial < 0; r0 += G) {
+        const int j = r0 + gl + 1;              // trial number, 1-based
+        const bool valid = j <= ntrials;
+        const bool closed = (!LEGACY) || (j == 1);    // LEGACY trials >= 2 run open loop on accumulated controls
+        if (LEGACY) {
+          // Accumulated controls of the open-loop trials of this round, nodes in parallel:
+          //   u_i = u_{i-1} + 2^-(i-1) k   (ilqr.py:119 with new_u aliasing u); lane i-1-r0 rolls u_i out.
+          const int first = (r0 == 0) ? 2 : r0 + 1;
+          const int last = (r0 + G < ntrials) ? r0 + G : ntrials;
+          const bool from_cur = (r0 == 0) || (G == 1 && r0 == 1);
+          for (int t = gl; t < H && first <= last; t += G) {
+            const double* rt = rec(t);
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+              const double kf = rt[(size_t)(RL::rk + r) * ES];
+              double s = from_cur ? rt[(size_t)(RL::ru + r) * ES] : *ucum_at(t * M + r, gid * G + (G - 1));
+              double al = alpha_of(first);
+              for (int i = first; i <= last; ++i) {
+                s = s + al * kf;
+                al = al / 2.0;
+                *ucum_at(t * M + r, gid * G + (i - 1 - r0)) = s;
+              }
+            }
+          }
+          __threadfence_block();
+        }
+        const double J = rollout(valid, closed, alpha_of(j), lg, valid ? store_slot(j) : -1);
         const bool ok = valid && (J < old_cost);
         int w = gfirst<G>(ok, lane);
         int nv = ntrials - r0; if (nv > G) nv = G;      // trials evaluated this round
         if (w >= 0) {
-          win_lane = w;
+          win_lane = w; win_trial = r0 + w + 1;
           new_cost = gbcast<G>(J, w);
           n_trials += w + 1;
         } else {
           n_trials += nv;
           if (LEGACY && r0 + G >= ntrials) {
             // every step rejected: the reference is left holding the last trial's arrays (ilqr.py:137-147)
-            win_lane = nv - 1;
+            win_lane = nv - 1; win_trial = ntrials;
             new_cost = gbcast<G>(J, win_lane);
           }
         }
       }
-      if (win_lane >= 0) { cur_lane = win_lane; cur_par = np_; }
+      if (win_trial >= 0) {
+        int ws = store_slot(win_trial);
+        if (ws < 0) {
+          // an unusual winner: every lane of the group repeats its roll-out, lane 0 keeps it in the spare slot
+          __threadfence_block();
+          (void)rollout(true, (!LEGACY) || (win_trial == 1), alpha_of(win_trial), gid * G + win_lane, (gl == 0) ? SS - 1 : -1);
+          ws = SS - 1;
+        }
+        cur_slot = ws; cur_par = np_;
+      }
       __threadfence_block();
 
       PROF_MARK(4)
@@ -1088,9 +1119,8 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
       const bool brk = fabs(new_cost - old_cost) < a.prm.inner_tol;
       if (!brk) {
         // x, u = new_x, new_u : the pair optimize() will return
-        const size_t ns = gid * G + cur_lane;
-        for (int e = gl; e < XS; e += G) a.x_out[(size_t)p * XS + e] = *trj_at(cur_par, e, ns);
-        for (int e = gl; e < US; e += G) a.u_out[(size_t)p * US + e] = *trj_at(cur_par, XS + e, ns);
+        for (int e = gl; e < XS; e += G) a.x_out[(size_t)p * XS + e] = *trj_at(cur_par, e, cur_slot);
+        for (int e = gl; e < US; e += G) a.u_out[(size_t)p * US + e] = *trj_at(cur_par, XS + e, cur_slot);
         old_cost = new_cost;
       }
       bool finished = false;
@@ -1135,10 +1165,9 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         }
       }
       if (finished) {
-        const size_t ns = gid * G + cur_lane;
         double fc = total_cost();
-        if (a.node_x) for (int e = gl; e < XS; e += G) a.node_x[(size_t)p * XS + e] = *trj_at(cur_par, e, ns);
-        if (a.node_u) for (int e = gl; e < US; e += G) a.node_u[(size_t)p * US + e] = *trj_at(cur_par, XS + e, ns);
+        if (a.node_x) for (int e = gl; e < XS; e += G) a.node_x[(size_t)p * XS + e] = *trj_at(cur_par, e, cur_slot);
+        if (a.node_u) for (int e = gl; e < US; e += G) a.node_u[(size_t)p * US + e] = *trj_at(cur_par, XS + e, cur_slot);
         if (a.lam)
           for (int e = gl; e < (H + 1) * C; e += G)
             a.lam[(size_t)p * (H + 1) * C + e] = rec(e / C)[(size_t)(RL::rl + e % C) * ES];

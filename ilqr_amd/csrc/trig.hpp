@@ -52,7 +52,56 @@ __device__ __forceinline__ void sincos_w(double x, double* s, double* c) {
   *c = ((n + 1) & 2) ? -cc : cc;
 }
 
+// |x| <= 4 assumed (wrapped angles); NaN in, NaN out.  No large-argument path.
+__device__ __forceinline__ void sincos_pi(double x, double* s, double* c) {
+  const double q = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-q, 1.57079632679489655800e+00, x);
+  r = fma(-q, 6.12323399573676603587e-17, r);
+  double sr, cr;
+  sincos_kernels(r, &sr, &cr);
+  const int n = (int)q;
+  const double ss = (n & 1) ? cr : sr;
+  const double cc = (n & 1) ? sr : cr;
+  *s = (n & 2) ? -ss : ss;
+  *c = ((n + 1) & 2) ? -cc : cc;
+}
+
+// tan on |x| < 0.67434 by the odd minimax polynomial of the fdlibm tangent kernel (< 1 ulp)
+__device__ __forceinline__ double tan_poly(double x) {
+  const double T0 = 3.33333333333334091986e-01, T1 = 1.33333333333201242699e-01, T2 = 5.39682539762260521377e-02,
+               T3 = 2.18694882948595424599e-02, T4 = 8.86323982359930005737e-03, T5 = 3.59207910759131235356e-03,
+               T6 = 1.45620945432529025516e-03, T7 = 5.88041240820264096874e-04, T8 = 2.46463134818469906812e-04,
+               T9 = 7.81794442939557092300e-05, T10 = 7.14072491382608190305e-05, T11 = -1.85586374855275456654e-05,
+               T12 = 2.59073051863633712884e-05;
+  const double z = x * x;
+  const double w = z * z;
+  double r = fma(w, T11, T9);
+  r = fma(w, r, T7);
+  r = fma(w, r, T5);
+  r = fma(w, r, T3);
+  r = fma(w, r, T1);
+  double v = fma(w, T12, T10);
+  v = fma(w, v, T8);
+  v = fma(w, v, T6);
+  v = fma(w, v, T4);
+  v = fma(w, v, T2);
+  v = z * v;
+  const double s3 = z * x;
+  r = z * (s3 * (r + v));
+  r = fma(T0, s3, r);
+  return x + r;
+}
+
+// tan for wrapped angles (|x| <= 4 or NaN): polynomial on small angles, sin/cos beyond
+__device__ __forceinline__ double tan_pi(double x) {
+  if (__builtin_expect(fabs(x) < 0.67434, 1)) return tan_poly(x);
+  double s, c;
+  sincos_pi(x, &s, &c);
+  return s / c;
+}
+
 __device__ __forceinline__ double tan_w(double x) {
+  if (__builtin_expect(fabs(x) < 0.67434, 1)) return tan_poly(x);
   if (__builtin_expect(!(fabs(x) <= 4.0), 0)) return tan(x);
   double s, c;
   sincos_w(x, &s, &c);
