@@ -11,9 +11,10 @@ import numpy as np
 ABI_VERSION = 1
 STATUS_WORDS = 4
 
-MODELS = {"lat": 0, "kin": 1, "dyn": 2, "dyn_mid": 3, "lat_k": 4}
+MODELS = {"lat": 0, "kin": 1, "dyn": 2, "dyn_mid": 3, "lat_k": 4, "new_bicycle": 5}
 MODES = {"legacy": 0, "fast": 1, "new_al": 2}
-MODEL_DIMS = {0: (4, 1), 1: (6, 2), 2: (6, 2), 3: (6, 2), 4: (4, 1)}
+MODEL_DIMS = {0: (4, 1), 1: (6, 2), 2: (6, 2), 3: (6, 2), 4: (4, 1), 5: (6, 2)}
+DV_GATE = 0.20000000298023224   # the float literal 0.2F of new_al_ilqr.h:1039, as a double
 
 FLAG_VIOL_OK = 1
 FLAG_OUTER_CAP = 2
@@ -44,11 +45,11 @@ def default_params(mode):
     new_al_ilqr.h:1177-1211)."""
     mode = MODES[mode] if isinstance(mode, str) else int(mode)
     if mode == MODES["legacy"]:
-        return Params(20, 20, 1e-8, 1e-3, 1e-1, 8.0, 1e-9, 1e-8, 20.0, 0.2)
+        return Params(20, 20, 1e-8, 1e-3, 1e-1, 8.0, 1e-9, 1e-8, 20.0, DV_GATE)
     if mode == MODES["fast"]:
-        return Params(20, 20, 1e-8, 1e-3, 1e-1, 8.0, 0.0, 1e-8, 20.0, 0.2)
+        return Params(20, 20, 1e-8, 1e-3, 1e-1, 8.0, 0.0, 1e-8, 20.0, DV_GATE)
     if mode == MODES["new_al"]:
-        return Params(50, 100, 1e-3, 1e-4, 5e-4, 100.0, 0.0, 1e-8, 20.0, 0.2)
+        return Params(50, 100, 1e-3, 1e-4, 5e-4, 100.0, 0.0, 1e-8, 20.0, DV_GATE)
     raise ValueError(f"unknown solver mode {mode}")
 
 

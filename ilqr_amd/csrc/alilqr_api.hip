@@ -46,10 +46,12 @@ struct Dims {
 bool model_dims(int model, Dims* d) {
   using namespace alilqr;
   switch (model) {
-    case ALILQR_MODEL_LAT: *d = {4, 1, Model<ALILQR_MODEL_LAT>::NA, Model<ALILQR_MODEL_LAT>::NB, LinLayout<Model<ALILQR_MODEL_LAT>>::E}; return true;
+    case ALILQR_MODEL_LAT:
+    case ALILQR_MODEL_LAT_K: *d = {4, 1, Model<ALILQR_MODEL_LAT>::NA, Model<ALILQR_MODEL_LAT>::NB, LinLayout<Model<ALILQR_MODEL_LAT>>::E}; return true;
     case ALILQR_MODEL_KIN:
     case ALILQR_MODEL_DYN:
-    case ALILQR_MODEL_DYN_MID: *d = {6, 2, Model<ALILQR_MODEL_KIN>::NA, Model<ALILQR_MODEL_KIN>::NB, LinLayout<Model<ALILQR_MODEL_KIN>>::E}; return true;
+    case ALILQR_MODEL_DYN_MID:
+    case ALILQR_MODEL_NEW_BICYCLE: *d = {6, 2, Model<ALILQR_MODEL_KIN>::NA, Model<ALILQR_MODEL_KIN>::NB, LinLayout<Model<ALILQR_MODEL_KIN>>::E}; return true;
     default: return false;
   }
 }
@@ -64,10 +66,18 @@ int32_t check_problem(const alilqr_problem* p, Dims* d) {
   if (p->table_nodes != 1 && p->table_nodes != p->horizon + 1) { set_err("table_nodes must be 1 or horizon+1"); return ALILQR_E_ARG; }
   if (p->mode == ALILQR_MODE_LEGACY) {
     if (p->c != 2 * (p->n + p->m)) { set_err("LEGACY needs c = 2(n+m)"); return ALILQR_E_ARG; }
-    if (p->model == ALILQR_MODEL_DYN_MID) { set_err("LEGACY is defined for LAT, KIN, DYN"); return ALILQR_E_ARG; }
+    if (p->model != ALILQR_MODEL_LAT && p->model != ALILQR_MODEL_KIN && p->model != ALILQR_MODEL_DYN) {
+      set_err("LEGACY is defined for LAT, KIN, DYN"); return ALILQR_E_ARG;
+    }
   } else if (p->mode == ALILQR_MODE_FAST) {
     if (p->c < 1 || p->c > 64) { set_err("FAST needs 1 <= c <= 64"); return ALILQR_E_ARG; }
     if (p->model != ALILQR_MODEL_DYN_MID) { set_err("FAST is defined for DYN_MID"); return ALILQR_E_ARG; }
+  } else if (p->mode == ALILQR_MODE_NEW_AL) {
+    if (!std::getenv("ALILQR_ENABLE_NEW_AL")) { set_err("NEW_AL is not enabled in this build"); return ALILQR_E_ARG; }
+    if (p->c < 1 || p->c > 64) { set_err("NEW_AL needs 1 <= c <= 64"); return ALILQR_E_ARG; }
+    if (p->model != ALILQR_MODEL_LAT_K && p->model != ALILQR_MODEL_NEW_BICYCLE) {
+      set_err("NEW_AL is defined for LAT_K, NEW_BICYCLE"); return ALILQR_E_ARG;
+    }
   } else {
     set_err("unsupported solver mode"); return ALILQR_E_ARG;
   }
@@ -102,6 +112,10 @@ size_t block_doubles_for(const alilqr_problem* p) {
   if (p->mode == ALILQR_MODE_LEGACY) {
     if (p->model == ALILQR_MODEL_LAT) return block_doubles<Model<ALILQR_MODEL_LAT>, ALILQR_MODE_LEGACY>(H, C);
     return block_doubles<Model<ALILQR_MODEL_KIN>, ALILQR_MODE_LEGACY>(H, C);
+  }
+  if (p->mode == ALILQR_MODE_NEW_AL) {
+    if (p->model == ALILQR_MODEL_LAT_K) return block_doubles<Model<ALILQR_MODEL_LAT_K>, ALILQR_MODE_NEW_AL>(H, C);
+    return block_doubles<Model<ALILQR_MODEL_NEW_BICYCLE>, ALILQR_MODE_NEW_AL>(H, C);
   }
   return block_doubles<Model<ALILQR_MODEL_DYN_MID>, ALILQR_MODE_FAST>(H, C);
 }
@@ -178,9 +192,11 @@ __global__ __launch_bounds__(256) void linearize_kernel(LArgs a) {
   MD::step(a.mc, x, u, xn);
   MD::jac(a.mc, x, u, ac, bc);
   expand_jac<MD>(a.mc, ac, bc, S, Bm);
-  // the node keeps its state angle-wrapped from its first cost call on
-  x[2] = wrap_py(x[2]);
-  x[3] = wrap_py(x[3]);
+  if (MODE != ALILQR_MODE_NEW_AL) {
+    // the Python node keeps its state angle-wrapped from its first cost call on
+    x[2] = wrap_py(x[2]);
+    x[3] = wrap_py(x[3]);
+  }
   const double* g = a.goals + ((a.goal_batch > 1) ? (size_t)b * (a.H + 1) * N : 0) + (size_t)t * N;
   ctab Q = as_ctab(a.Q) + (size_t)tt * N * N;
   ctab R = as_ctab(a.R) + (size_t)tt * M * M;
@@ -223,7 +239,7 @@ int32_t alilqr_default_params(int32_t mode, alilqr_params* out) {
   if (!out) { set_err("null params"); return ALILQR_E_ARG; }
   alilqr_params p{};
   p.init_r = 20.0;
-  p.dv_gate = 0.2;
+  p.dv_gate = (double)0.2F;   /* new_al_ilqr.h:1039 compares with a float literal */
   p.alpha_min = 1e-8;
   switch (mode) {
     case ALILQR_MODE_LEGACY:
@@ -311,6 +327,9 @@ int32_t alilqr_solve_batch(const alilqr_problem* p,
     }
   } else if (p->mode == ALILQR_MODE_FAST) {
     if (p->model == ALILQR_MODEL_DYN_MID) return launch_g<ALILQR_MODEL_DYN_MID, ALILQR_MODE_FAST>(ka, pl.G, waves, st);
+  } else if (p->mode == ALILQR_MODE_NEW_AL) {
+    if (p->model == ALILQR_MODEL_LAT_K) return launch_g<ALILQR_MODEL_LAT_K, ALILQR_MODE_NEW_AL>(ka, pl.G, waves, st);
+    if (p->model == ALILQR_MODEL_NEW_BICYCLE) return launch_g<ALILQR_MODEL_NEW_BICYCLE, ALILQR_MODE_NEW_AL>(ka, pl.G, waves, st);
   }
   set_err("unsupported model / mode combination");
   return ALILQR_E_ARG;
@@ -347,6 +366,9 @@ int32_t alilqr_linearize_batch(const alilqr_problem* p,
       case ALILQR_MODEL_DYN: hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_DYN, ALILQR_MODE_LEGACY>), grid, block, 0, st, a); break;
       default: set_err("unsupported model / mode combination"); return ALILQR_E_ARG;
     }
+  } else if (p->mode == ALILQR_MODE_NEW_AL) {
+    if (p->model == ALILQR_MODEL_LAT_K) hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_LAT_K, ALILQR_MODE_NEW_AL>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_NEW_BICYCLE, ALILQR_MODE_NEW_AL>), grid, block, 0, st, a);
   } else {
     hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_DYN_MID, ALILQR_MODE_FAST>), grid, block, 0, st, a);
   }

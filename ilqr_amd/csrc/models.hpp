@@ -14,6 +14,7 @@
 //   KIN      cilqr/full_bicycle_kinematic_node.py:31-105
 //   DYN      cilqr/full_bicycle_dynamic_node.py:32-108
 //   DYN_MID  cilqr/fast_bicycle_node.py:27-139
+//   LAT_K / NEW_BICYCLE  al_ilqr_cpp/model/new_lat_bicycle_node.h, new_bicycle_node.h
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/alilqr.h"
@@ -236,5 +237,214 @@ struct Full6 : Full6Base {
 template <> struct Model<ALILQR_MODEL_KIN> : Full6<ALILQR_MODEL_KIN> {};
 template <> struct Model<ALILQR_MODEL_DYN> : Full6<ALILQR_MODEL_DYN> {};
 template <> struct Model<ALILQR_MODEL_DYN_MID> : Full6<ALILQR_MODEL_DYN_MID> {};
+
+// ---------------------------------------------------------------------------
+// Models of the C++ generation (NEW_AL).  Differences to the Python nodes:
+//   * angle wrap: identity inside (-pi, pi), C fmod (sign of the dividend) outside
+//     (al_ilqr_cpp/model/new_ilqr_node.h:32-37)
+//   * the lateral model carries the constant (1 + k v^2) factor
+//   * f_xx of the first three state rows for the Riccati recursion
+//   * an unwrapped "parallel" step used by the five-wide line-search ladder
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wrap_c(double a) {
+  if (fabs(a) < 3.14159265358979323846) return a;
+  return fmod(a + 3.14159265358979323846, 2 * 3.14159265358979323846) - 3.14159265358979323846;
+}
+
+template <>
+struct Model<ALILQR_MODEL_LAT_K> : Lat4Base {
+  static constexpr int NF = 7;   // f_xx entries: x(2,2) x(2,3) x(3,3) y(2,2) y(2,3) y(3,3) theta(3,3)
+  __device__ static void cont(const ModelConst& mc, const double* s, const double* u, double* out) {
+    double th = wrap_c(s[2]), de = wrap_c(s[3]);
+    double sn, cs;
+    sincos_w(th, &sn, &cs);
+    out[0] = mc.v * cs;
+    out[1] = mc.v * sn;
+    out[2] = mc.v * tan_w(de) / (mc.L * (1 + mc.k * mc.v * mc.v));
+    out[3] = u[0];
+  }
+  template <bool WRAPPED = false>
+  __device__ static void step(const ModelConst& mc, const double* x, const double* u, double* xn) {
+    double k1[4], k2[4], mid[4];
+    cont(mc, x, u, k1);
+    const double hdt = 0.5 * mc.dt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mid[i] = x[i] + hdt * k1[i];
+    cont(mc, mid, u, k2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xn[i] = x[i] + mc.dt * k2[i];
+    xn[2] = wrap_c(xn[2]);
+    xn[3] = wrap_c(xn[3]);
+  }
+  // one column of parallel_dynamics: no wrap at all (new_lat_bicycle_node.h:60-87)
+  __device__ static void par_cont(const ModelConst& mc, const double* s, const double* u, double* out) {
+    const double denom = mc.L * (1.0 + mc.k * mc.v * mc.v);
+    double sn, cs;
+    sincos_w(s[2], &sn, &cs);
+    out[0] = mc.v * cs;
+    out[1] = mc.v * sn;
+    out[2] = mc.v * tan_w(s[3]) / denom;
+    out[3] = u[0];
+  }
+  __device__ static void par_step(const ModelConst& mc, const double* x, const double* u, double* xn) {
+    double k1[4], k2[4], mid[4];
+    par_cont(mc, x, u, k1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mid[i] = x[i] + k1[i] * mc.dt * 0.5;
+    par_cont(mc, mid, u, k2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xn[i] = x[i] + k2[i] * mc.dt;
+  }
+  template <bool WRAPPED = false>
+  __device__ static void jac(const ModelConst& mc, const double* x, const double* uc, double* a, double* b) {
+    const double v = mc.v, dt = mc.dt, L = mc.L, k = mc.k;
+    double theta = wrap_c(x[2]), delta = wrap_c(x[3]);
+    double u1 = uc[0];
+    double tan_delta = tan_w(delta);
+    double theta_mid = theta + 0.5 * dt * v * tan_delta / (L * (k * v * v + 1));
+    double tan_delta_mid = tan_w(delta + 0.5 * dt * u1);
+    double denom = L * (k * v * v + 1);
+    double sn, cs;
+    sincos_w(theta_mid, &sn, &cs);
+    double t2 = tan_delta * tan_delta, tm2 = tan_delta_mid * tan_delta_mid;
+    a[0] = -dt * v * sn;
+    a[1] = -0.5 * dt * dt * v * v * (t2 + 1) * sn / denom;
+    a[2] = dt * v * cs;
+    a[3] = 0.5 * dt * dt * v * v * (t2 + 1) * cs / denom;
+    a[4] = dt * v * (tm2 + 1) / denom;
+    b[0] = 0.5 * dt * dt * v * (tm2 + 1) / denom;
+  }
+  // new_lat_bicycle_node.h:128-163
+  __device__ static void fxx(const ModelConst& mc, const double* x, const double* uc, double* f) {
+    const double v = mc.v, dt = mc.dt, L = mc.L, k = mc.k;
+    (void)uc;
+    double theta = wrap_c(x[2]), delta = wrap_c(x[3]);
+    double td = tan_w(delta), t2 = td * td;
+    double theta_mid = theta + 0.5 * dt * v * td / (L * (k * v * v + 1));
+    double denom = L * (k * v * v + 1);
+    double sn, cs;
+    sincos_w(theta_mid, &sn, &cs);
+    f[0] = -dt * v * cs;
+    f[1] = -0.5 * dt * dt * v * v * (t2 + 1) * cs / denom;
+    f[2] = -dt * dt * v * v * ((t2 + 1) / denom) * (0.5 * v * (t2 + 1) * cs / denom + sn * td);
+    f[3] = -dt * v * sn;
+    f[4] = -0.5 * dt * dt * v * v * (t2 + 1) * sn / denom;
+    f[5] = dt * dt * v * v * ((t2 + 1) / denom) * (cs * td - 0.5 * v * (t2 + 1) * sn / denom);
+    f[6] = 2 * dt * v * (t2 + 1) * td / denom;
+  }
+  // (F0 Vx0 + F1 Vx1) + F2 Vx2 at entry (i,j), zero entries dropped   (new_al_ilqr.h:954-956)
+  __device__ static __forceinline__ double fxx_term(const double* f, const double* Vx, int i, int j) {
+    if (i == 2 && j == 2) return f[0] * Vx[0] + f[3] * Vx[1];
+    if ((i == 2 && j == 3) || (i == 3 && j == 2)) return f[1] * Vx[0] + f[4] * Vx[1];
+    if (i == 3 && j == 3) return (f[2] * Vx[0] + f[5] * Vx[1]) + f[6] * Vx[2];
+    return 0.0;
+  }
+  __host__ __device__ static constexpr bool fxx_nz(int i, int j) { return (i == 2 || i == 3) && (j == 2 || j == 3); }
+};
+
+template <>
+struct Model<ALILQR_MODEL_NEW_BICYCLE> : Full6Base {
+  static constexpr int NF = 7;   // f_xx entries: x(2,2) x(2,4) y(2,2) y(2,4) theta(3,3) theta(3,4) theta(4,4)
+  __device__ static void cont(const ModelConst& mc, const double* s, const double* u, double* out) {
+    double th = wrap_c(s[2]), de = wrap_c(s[3]);
+    double v = s[4], acc = s[5];
+    double sn, cs;
+    sincos_w(th, &sn, &cs);
+    out[0] = v * cs;
+    out[1] = v * sn;
+    out[2] = v * tan_w(de) / (mc.L * (1 + mc.k * v * v));
+    out[3] = u[0];
+    out[4] = acc;
+    out[5] = u[1];
+  }
+  template <bool WRAPPED = false>
+  __device__ static void step(const ModelConst& mc, const double* x, const double* u, double* xn) {
+    double k1[6], k2[6], mid[6];
+    cont(mc, x, u, k1);
+    const double hdt = 0.5 * mc.dt;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) mid[i] = x[i] + hdt * k1[i];
+    cont(mc, mid, u, k2);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xn[i] = x[i] + mc.dt * k2[i];
+    xn[2] = wrap_c(xn[2]);
+    xn[3] = wrap_c(xn[3]);
+  }
+  // new_bicycle_node.h:285-377
+  __device__ static void par_cont(const ModelConst& mc, const double* s, const double* u, double* out) {
+    double v = s[4];
+    double sn, cs;
+    sincos_w(s[2], &sn, &cs);
+    out[0] = v * cs;
+    out[1] = v * sn;
+    out[2] = v * tan_w(s[3]) * (1.0 / (1.0 + mc.k * v * v)) / mc.L;
+    out[3] = u[0];
+    out[4] = s[5];
+    out[5] = u[1];
+  }
+  __device__ static void par_step(const ModelConst& mc, const double* x, const double* u, double* xn) {
+    double k1[6], k2[6], mid[6];
+    par_cont(mc, x, u, k1);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) mid[i] = x[i] + k1[i] * mc.dt * 0.5;
+    par_cont(mc, mid, u, k2);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xn[i] = x[i] + k2[i] * mc.dt;
+  }
+  // new_bicycle_node.h:492-545
+  template <bool WRAPPED = false>
+  __device__ static void jac(const ModelConst& mc, const double* x, const double* uc, double* a, double* b) {
+    const double dt = mc.dt, L = mc.L, k = mc.k;
+    double theta = wrap_c(x[2]), delta = wrap_c(x[3]);
+    double v = x[4], acc = x[5], u1 = uc[0];
+    double D = L * (k * v * v + 1);
+    double td = tan_w(delta), tu = tan_w(delta + 0.5 * dt * u1);
+    double tm = theta + 0.5 * dt * v * td / D;
+    double vt = 0.5 * acc * dt + v;
+    double Dm = L * (k * vt * vt + 1);
+    double sn, cs;
+    sincos_w(tm, &sn, &cs);
+    double g = -1.0 * dt * k * v * v * td / (L * (k * v * v + 1) * (k * v * v + 1)) + 0.5 * dt * td / D;
+    a[0] = -dt * vt * sn;
+    a[1] = -0.5 * dt * dt * v * vt * (td * td + 1) * sn / D;
+    a[2] = -dt * vt * g * sn + dt * cs;
+    a[3] = 0.5 * dt * dt * cs;
+    a[4] = dt * vt * cs;
+    a[5] = 0.5 * dt * dt * v * vt * (td * td + 1) * cs / D;
+    a[6] = dt * vt * g * cs + dt * sn;
+    a[7] = 0.5 * dt * dt * sn;
+    a[8] = dt * vt * (tu * tu + 1) / Dm;
+    a[9] = -dt * k * vt * (1.0 * acc * dt + 2 * v) * tu / (L * (k * vt * vt + 1) * (k * vt * vt + 1)) + dt * tu / Dm;
+    a[10] = -1.0 * dt * dt * k * vt * vt * tu / (L * (k * vt * vt + 1) * (k * vt * vt + 1)) + 0.5 * dt * dt * tu / Dm;
+    b[0] = 0.5 * dt * dt * vt * (tu * tu + 1) / Dm;
+  }
+  // new_bicycle_node.h:605-650 (Euler form)
+  __device__ static void fxx(const ModelConst& mc, const double* x, const double* uc, double* f) {
+    const double dt = mc.dt, L = mc.L, k = mc.k;
+    (void)uc;
+    double theta = wrap_c(x[2]), delta = wrap_c(x[3]), v = x[4];
+    double sn, cs;
+    sincos_w(theta, &sn, &cs);
+    double td = tan_w(delta);
+    double tp1 = td * td + 1;
+    double kv2 = k * v * v, kp1 = kv2 + 1;
+    f[0] = -dt * v * cs;
+    f[1] = -dt * sn;
+    f[2] = -dt * v * sn;
+    f[3] = dt * cs;
+    f[4] = 2 * dt * v * tp1 * td / (kp1 * L);
+    f[5] = dt * (1 - k * v * v) * tp1 / (kp1 * L) / (kp1);
+    f[6] = dt * 2 * k * v * (kv2 - 3) * td / L / kp1 / kp1 / kp1;
+  }
+  __device__ static __forceinline__ double fxx_term(const double* f, const double* Vx, int i, int j) {
+    if (i == 2 && j == 2) return f[0] * Vx[0] + f[2] * Vx[1];
+    if ((i == 2 && j == 4) || (i == 4 && j == 2)) return f[1] * Vx[0] + f[3] * Vx[1];
+    if (i == 3 && j == 3) return f[4] * Vx[2];
+    if ((i == 3 && j == 4) || (i == 4 && j == 3)) return f[5] * Vx[2];
+    if (i == 4 && j == 4) return f[6] * Vx[2];
+    return 0.0;
+  }
+  __host__ __device__ static constexpr bool fxx_nz(int i, int j) { return (i >= 2 && i <= 4) && (j >= 2 && j <= 4); }
+};
 
 }  // namespace alilqr

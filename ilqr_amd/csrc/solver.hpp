@@ -179,13 +179,15 @@ __device__ __forceinline__ void inv_small(const double (&Qm)[M][M], double (&Qi)
 }
 
 // One step of the backward recursion (cilqr/ilqr.py:85-98).
-template <class MD, class FLx, class FLu, class FLxx, class FLuu>
+template <class MD, class FLx, class FLu, class FLxx, class FLuu, class FXtra>
 __device__ __forceinline__ void riccati_step(const double (&S)[MD::N][MD::N], const double (&Bm)[MD::N][MD::M],
-                                             FLx lx, FLu lu, FLxx lxx, FLuu luu, double reg,
+                                             FLx lx, FLu lu, FLxx lxx, FLuu luu, FXtra xtra, double reg, double* dv_lin,
                                              double (&Vx)[MD::N], double (&Vxx)[MD::N][MD::N],
                                              double (&K)[MD::M][MD::N], double (&kf)[MD::M]) {
   constexpr int N = MD::N, M = MD::M;
-  double Qx[N], Qu[M];
+  double Qx[N], Qu[M], Vo[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) Vo[i] = Vx[i];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     double acc = lx(i) + Vx[i];
@@ -278,6 +280,7 @@ __device__ __forceinline__ void riccati_step(const double (&S)[MD::N][MD::N], co
 #pragma unroll
       for (int k = 0; k < N; ++k)
         if (s_nz<MD>(k, i)) acc = fma(S[k][i], W[k][j], acc);
+      acc = xtra(acc, i, j, Vo);          // f_xx contraction of the C++ generation (identity elsewhere)
 #pragma unroll
       for (int a = 0; a < M; ++a) acc = fma(K[a][i], QK[a][j], acc);
 #pragma unroll
@@ -290,6 +293,10 @@ __device__ __forceinline__ void riccati_step(const double (&S)[MD::N][MD::N], co
   for (int i = 0; i < N; ++i)
 #pragma unroll
     for (int j = 0; j < N; ++j) Vxx[i][j] = Vn[i][j];
+  double dl = 0.0;
+#pragma unroll
+  for (int a = 0; a < M; ++a) dl += kf[a] * Qu[a];
+  *dv_lin = dl;
 }
 
 // ---------------------------------------------------------------------------
@@ -554,6 +561,135 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
   }
 };
 
+
+// NEW_AL: the C++ generation (al_ilqr_cpp/constraints/constraints.h:514-1040, model/new_bicycle_node.h:702-910).
+// Same projection-form AL as FAST with three differences: only diag(Q), diag(R) enter the cost, the active-row
+// mask is "projected multiplier < 0" (a row sitting exactly at zero drops out), and the state is not wrapped.
+template <int MODEL>
+struct NodeOps<MODEL, ALILQR_MODE_NEW_AL> {
+  using MD = Model<MODEL>;
+  static constexpr int N = MD::N, M = MD::M;
+
+  __device__ static __forceinline__ double cval(const KArgs& a, ctab tab, const double* x, const double* u, int i) {
+    ctab A = tab, Bm = tab + a.C * N, Cv = tab + a.C * (N + M);
+    double ax = 0.0, bu = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) ax += A[i * N + j] * x[j];
+#pragma unroll
+    for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
+    return ax + bu + Cv[i];
+  }
+  __device__ static double cost(const KArgs& a, ctab Q, ctab R, ctab tab,
+                                const double* x, const double* u, const double* g,
+                                const double* lam, size_t ls, double mu) {
+    double sc = 0.0, cc = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { double e = x[i] - g[i]; sc += (e * Q[i * N + i]) * e; }
+#pragma unroll
+    for (int j = 0; j < M; ++j) cc += (R[j * M + j] * u[j]) * u[j];
+    double pp = 0.0, ll = 0.0;
+    for (int i = 0; i < a.C; ++i) {
+      double l = lam[i * ls];
+      double lp = fmin(l - mu * cval(a, tab, x, u, i), 0.0);
+      pp += lp * lp;
+      ll += l * l;
+    }
+    return sc + cc + 0.5 / mu * (pp - ll);
+  }
+  // one column of parallel_cost / parallel_augmented_lagrangian_cost (constraints.h:558-580)
+  __device__ static double par_cost(const KArgs& a, ctab Q, ctab R, ctab tab,
+                                    const double* x, const double* u, const double* g,
+                                    const double* lam, size_t ls, double mu) {
+    double cq = 0.0, cr = 0.0, al = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { double e = x[i] - g[i]; cq += e * (e * Q[i * N + i]); }
+#pragma unroll
+    for (int j = 0; j < M; ++j) cr += (R[j * M + j] * u[j]) * u[j];
+    for (int i = 0; i < a.C; ++i) {
+      double l = lam[i * ls];
+      double pr = fmin(l - mu * cval(a, tab, x, u, i), 0.0);
+      al += pr * pr - l * l;
+    }
+    al = 0.5 / mu * al;
+    return (cq + cr) + al;
+  }
+  __device__ static void quadratize(const KArgs& a, ctab Q, ctab R, ctab tab,
+                                    const double* x, const double* u, const double* g,
+                                    const double* lam, size_t ls, double mu,
+                                    double* rec, size_t rs) {
+    using LL = LinLayout<MD>;
+    ctab A = tab, Bm = tab + a.C * N;
+    double e[N], jx[N], ju[M], hx[N][N], hu[M][M];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { e[i] = x[i] - g[i]; jx[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < M; ++i) ju[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < N; ++j) hx[i][j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = 0; j < M; ++j) hu[i][j] = 0.0;
+    for (int i = 0; i < a.C; ++i) {
+      double lp = fmin(lam[i * ls] - mu * cval(a, tab, x, u, i), 0.0);
+      double on = (lp >= 0.0) ? 0.0 : 1.0;
+      double pa[N], pb[M];
+#pragma unroll
+      for (int j = 0; j < N; ++j) { pa[j] = on * A[i * N + j]; jx[j] += pa[j] * lp; }
+#pragma unroll
+      for (int j = 0; j < M; ++j) { pb[j] = on * Bm[i * M + j]; ju[j] += pb[j] * lp; }
+#pragma unroll
+      for (int p = 0; p < N; ++p)
+#pragma unroll
+        for (int q = 0; q < N; ++q) hx[p][q] += (mu * pa[p]) * A[i * N + q];
+#pragma unroll
+      for (int p = 0; p < M; ++p)
+#pragma unroll
+        for (int q = 0; q < M; ++q) hu[p][q] += (mu * pb[p]) * Bm[i * M + q];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) s += (2 * Q[i * N + j]) * e[j];
+      rec[(LL::oLx + i) * rs] = s + (-jx[i]);
+#pragma unroll
+      for (int j = 0; j < N; ++j) rec[(LL::oLxx + i * N + j) * rs] = 2 * Q[i * N + j] + hx[i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < M; ++j) s += (2 * R[i * M + j]) * u[j];
+      rec[(LL::oLu + i) * rs] = s + (-ju[i]);
+#pragma unroll
+      for (int j = 0; j < M; ++j) rec[(LL::oLuu + i * M + j) * rs] = 2 * R[i * M + j] + hu[i][j];
+    }
+  }
+  __device__ static double violation(const KArgs& a, ctab tab, const double* x, const double* u,
+                                     const double* lam, size_t ls, double mu) {
+    double v = 0.0;
+    for (int i = 0; i < a.C; ++i) {
+      double c = cval(a, tab, x, u, i);
+      double dc = fabs(c - fmin(c, 0.0));
+      v = (dc > v) ? dc : v;
+    }
+    (void)lam; (void)ls; (void)mu;
+    return v;
+  }
+  __device__ static double combine_violation(double acc, double node) { return (node > acc) ? node : acc; }
+  __device__ static double violation_init() { return -1.0; }
+  __device__ static void update_lambda(const KArgs& a, ctab tab, const double* x, const double* u,
+                                       double* lam, size_t ls, double mu) {
+    for (int i = 0; i < a.C; ++i) {
+      double c = cval(a, tab, x, u, i);
+      lam[i * ls] = fmin(lam[i * ls] - mu * c, 0.0);
+    }
+  }
+};
+
 // ---------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------
@@ -571,9 +707,10 @@ template <class MD, int MODE>
 struct NodeRec {
   static constexpr int N = MD::N, M = MD::M;
   static constexpr bool LEGACY = (MODE == ALILQR_MODE_LEGACY);
-  static constexpr int HX = LEGACY ? N : N * N, HU = LEGACY ? M : M * M;
+  static constexpr bool NEWAL = (MODE == ALILQR_MODE_NEW_AL);
+  static constexpr int HX = LEGACY ? N : N * N, HU = LEGACY ? M : M * M, NF = NEWAL ? 7 : 0;
   static constexpr int oA = 0, oB = oA + MD::NA, oLx = oB + MD::NB, oLu = oLx + N, oHx = oLu + M, oHu = oHx + HX,
-                       E = (oHu + HU + 1) & ~1;
+                       oF = oHu + HU, E = (oF + NF + 1) & ~1;
 };
 
 // doubles of one group's block (host and device must agree)
@@ -590,6 +727,20 @@ __host__ __device__ inline size_t block_doubles(int H, int C) {
 template <int MODE>
 struct TrjSlots { static constexpr int SS = (MODE == ALILQR_MODE_LEGACY) ? 4 : 8; };
 
+// f_xx of a node, only the C++ generation has it
+template <class MD, bool ON>
+struct FxxOf {
+  __device__ static __forceinline__ void eval(const ModelConst&, const double*, const double*, double*) {}
+  __device__ static __forceinline__ double add(double acc, const double*, const double*, int, int) { return acc; }
+};
+template <class MD>
+struct FxxOf<MD, true> {
+  __device__ static __forceinline__ void eval(const ModelConst& mc, const double* x, const double* u, double* f) { MD::fxx(mc, x, u, f); }
+  __device__ static __forceinline__ double add(double acc, const double* f, const double* Vx, int i, int j) {
+    return MD::fxx_nz(i, j) ? acc + MD::fxx_term(f, Vx, i, j) : acc;
+  }
+};
+
 template <int MODEL, int MODE, int G>
 __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) void solve_kernel(KArgs a) {
   using MD = Model<MODEL>;
@@ -599,6 +750,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   using NR = NodeRec<MD, MODE>;
   constexpr int N = MD::N, M = MD::M;
   constexpr bool LEGACY = (MODE == ALILQR_MODE_LEGACY);
+  constexpr bool NEWAL = (MODE == ALILQR_MODE_NEW_AL);
   constexpr bool PM = (G > 1);                         // block layout: problem-major (contiguous) or element-major
   constexpr int CL = LEGACY ? 2 * (N + M) : 1;         // multipliers held in registers (LEGACY only)
   constexpr int SS = TrjSlots<MODE>::SS;               // trajectory slots kept per problem and parity
@@ -635,12 +787,13 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   // number of line-search trials the reference can make: alpha = 1, 1/2, ... while alpha > alpha_min
   int ntrials = 0;
   for (double al = 1.0; al > a.prm.alpha_min && ntrials < 64; al = al / 2.0) ++ntrials;
+  if (NEWAL) ntrials = 10;                             // new_al_ilqr.h:1045
 
   // ---- per-group state (identical in every lane of a group) ----
   int p = -1;                 // problem being solved, -1: none
   bool drained = false;       // the batch counter ran out
   int cur_slot = 0, cur_par = 0;
-  double mu = 1.0, old_cost = 0.0, viol = 0.0;
+  double mu = 1.0, old_cost = 0.0, viol = 0.0, dv_lin = 0.0;
   int outer = 0, inner = 0, n_inner = 0, n_trials = 0;
   bool outer_start = false;
 
@@ -799,7 +952,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
               if (a.x_init) a.x_init[(size_t)p * XS + i] = x[i];
               a.x_out[(size_t)p * XS + i] = x[i];
               // node 0 keeps the wrapped start state from its first cost() call on (lat_bicycle_node.py:27-30,94)
-              *trj_at(0, i, cs) = (i == 2 || i == 3) ? wrap_py(x[i]) : x[i];
+              *trj_at(0, i, cs) = (!NEWAL && (i == 2 || i == 3)) ? wrap_py(x[i]) : x[i];
             }
           }
           for (int t = 0; t < H; ++t) {
@@ -864,11 +1017,17 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         for (int j = 0; j < M; ++j) r[(size_t)(RL::ru + j) * ES] = u[j];
         if (t < H) {
           double ac[MD::NA], bc[MD::NB];
-          MD::template jac<true>(mc, x, u, ac, bc);
+          MD::template jac<!NEWAL>(mc, x, u, ac, bc);
 #pragma unroll
           for (int i = 0; i < MD::NA; ++i) lr[(size_t)(NR::oA + i) * ES] = ac[i];
 #pragma unroll
           for (int i = 0; i < MD::NB; ++i) lr[(size_t)(NR::oB + i) * ES] = bc[i];
+          if (NEWAL) {
+            double ff[8];
+            FxxOf<MD, NEWAL>::eval(mc, x, u, ff);
+#pragma unroll
+            for (int i = 0; i < NR::NF; ++i) lr[(size_t)(NR::oF + i) * ES] = ff[i];
+          }
         }
         double q[LL::E];
         if (LEGACY) {
@@ -922,7 +1081,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         }
         auto sweep = [&](int t, const LinRegs& L, LinRegs& Lnext) {
           if (t > 0) load_lin(t - 1, Lnext);            // in flight while this step computes
-          double S[N][N], Bm[N][M], K[M][N], kf[M];
+          double S[N][N], Bm[N][M], K[M][N], kf[M], dl;
           expand_jac<MD>(mc, &L.v[NR::oA], &L.v[NR::oB], S, Bm);
           ctab Q = tabQ(t);
           ctab R = tabR(t);
@@ -931,7 +1090,9 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
                            [&](int r) { return L.v[NR::oLu + r]; },
                            [&](int i, int j) { return LEGACY ? ((i == j) ? L.v[NR::oHx + i] : 2 * Q[i * N + j]) : L.v[NR::oHx + i * N + j]; },
                            [&](int r, int b) { return LEGACY ? ((r == b) ? L.v[NR::oHu + r] : 2 * R[r * M + b]) : L.v[NR::oHu + r * M + b]; },
-                           a.prm.quu_reg, Vx, Vxx, K, kf);
+                           [&](double acc, int i, int j, const double* Vo) { return FxxOf<MD, NEWAL>::add(acc, &L.v[NR::oF], Vo, i, j); },
+                           a.prm.quu_reg, &dl, Vx, Vxx, K, kf);
+          dv_lin += dl;
           if (gl == 0) {
             double* rt = rec(t);
 #pragma unroll
@@ -942,6 +1103,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
             }
           }
         };
+        dv_lin = 0.0;
         LinRegs LA, LB;
         load_lin(H - 1, LA);
         int t = H - 1;
@@ -979,8 +1141,10 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         if (LEGACY) return (j == 1) ? 0 : (j == 2) ? 1 : (j == ntrials) ? 2 : -1;
         return (j <= SS - 1) ? j - 1 : -1;
       };
-      // roll out one trial: closed loop with step alpha, or open loop on the accumulated controls of lane `ul`
-      auto rollout = [&](bool valid, bool closed, double alpha, size_t ul, int sslot) -> double {
+      // roll out one trial.  kind 0: closed loop, step alpha (Python generations: (u + alpha k) + K dx;
+      // C++ generation: u + (K dx + alpha k)); kind 1: LEGACY open loop on the accumulated controls of
+      // lane `ul`; kind 2: one column of the C++ generation's five-wide ladder (no angle wrap, (u + K dx) + k alpha)
+      auto rollout = [&](bool valid, int kind, double alpha, size_t ul, int sslot) -> double {
         double J = 0.0;
         double x[N];
         RecRegs RA, RB;
@@ -992,30 +1156,42 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         }
         double uown[M];
 #pragma unroll
-        for (int r = 0; r < M; ++r) uown[r] = (!closed) ? *ucum_at(r, ul) : 0.0;
+        for (int r = 0; r < M; ++r) uown[r] = (LEGACY && kind == 1) ? *ucum_at(r, ul) : 0.0;
         auto roll = [&](int t, const RecRegs& R, RecRegs& Rn) {
           load_rec(t + 1, Rn);                         // next record in flight while this step computes
           double unext[M];
 #pragma unroll
-          for (int r = 0; r < M; ++r) unext[r] = (!closed && t + 1 < H) ? *ucum_at((t + 1) * M + r, ul) : 0.0;
+          for (int r = 0; r < M; ++r) unext[r] = (LEGACY && kind == 1 && t + 1 < H) ? *ucum_at((t + 1) * M + r, ul) : 0.0;
           double u[M];
-          if (closed) {
+          if (LEGACY && kind == 1) {
+#pragma unroll
+            for (int r = 0; r < M; ++r) u[r] = uown[r];
+          } else {
 #pragma unroll
             for (int r = 0; r < M; ++r) {
               double fb = 0.0;
 #pragma unroll
               for (int i = 0; i < N; ++i) fb += R.K[r][i] * (x[i] - R.x[i]);
-              u[r] = (R.u[r] + alpha * R.k[r]) + fb;
+              if (NEWAL) u[r] = (kind == 2) ? ((R.u[r] + fb) + R.k[r] * alpha) : (R.u[r] + (fb + alpha * R.k[r]));
+              else u[r] = (R.u[r] + alpha * R.k[r]) + fb;
             }
-          } else {
-#pragma unroll
-            for (int r = 0; r < M; ++r) u[r] = uown[r];
           }
           if (valid) {
-            if (LEGACY) J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, R.lam, 1, mu);
-            else J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, rec(t) + (size_t)RL::rl * ES, ES, mu);
             double xn[N];
-            MD::template step<true>(mc, x, u, xn);
+            if constexpr (NEWAL) {
+              const double* lp = rec(t) + (size_t)RL::rl * ES;
+              if (kind == 2) {
+                J += OPS::par_cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, lp, ES, mu);
+                MD::par_step(mc, x, u, xn);
+              } else {
+                J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, lp, ES, mu);
+                MD::template step<false>(mc, x, u, xn);
+              }
+            } else {
+              if (LEGACY) J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, R.lam, 1, mu);
+              else J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, rec(t) + (size_t)RL::rl * ES, ES, mu);
+              MD::template step<true>(mc, x, u, xn);
+            }
             if (sslot >= 0) {
 #pragma unroll
               for (int r = 0; r < M; ++r) *trj_at(np_, XS + t * M + r, sslot) = u[r];
@@ -1046,8 +1222,14 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
           double zu[M];
 #pragma unroll
           for (int r = 0; r < M; ++r) zu[r] = 0.0;
-          if (LEGACY) J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, RA.lam, 1, mu);
-          else J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, rec(H) + (size_t)RL::rl * ES, ES, mu);
+          if constexpr (NEWAL) {
+            const double* lp = rec(H) + (size_t)RL::rl * ES;
+            if (kind == 2) J += OPS::par_cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, lp, ES, mu);
+            else J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, lp, ES, mu);
+          } else {
+            if (LEGACY) J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, RA.lam, 1, mu);
+            else J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, rec(H) + (size_t)RL::rl * ES, ES, mu);
+          }
         }
         return J;
       };
@@ -1057,11 +1239,14 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         return al;
       };
       double new_cost = old_cost;
+      bool keep_old = false;                     // NEW_AL: the trial costs were not finite, the trajectory stays
       int win_trial = -1, win_lane = -1;
-      for (int r0 = 0; r0 < ntrials && win_trial < 0; r0 += G) {
+      double J_last = 0.0;
+      const bool gate_skip = NEWAL && (fabs(dv_lin) < a.prm.dv_gate);      // new_al_ilqr.h:1039
+      for (int r0 = 0; r0 < ntrials && win_trial < 0 && !gate_skip; r0 += G) {
         const int j = r0 + gl + 1;              // trial number, 1-based
         const bool valid = j <= ntrials;
-        const bool closed = (!LEGACY) || (j == 1);    // LEGACY trials >= 2 run open loop on accumulated controls
+        const int kind = (LEGACY && j != 1) ? 1 : 0;  // LEGACY trials >= 2 run open loop on accumulated controls
         if (LEGACY) {
           // Accumulated controls of the open-loop trials of this round, nodes in parallel:
           //   u_i = u_{i-1} + 2^-(i-1) k   (ilqr.py:119 with new_u aliasing u); lane i-1-r0 rolls u_i out.
@@ -1084,7 +1269,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
           }
           __threadfence_block();
         }
-        const double J = rollout(valid, closed, alpha_of(j), lg, valid ? store_slot(j) : -1);
+        const double J = rollout(valid, kind, alpha_of(j), lg, valid ? store_slot(j) : -1);
         const bool ok = valid && (J < old_cost);
         int w = gfirst<G>(ok, lane);
         int nv = ntrials - r0; if (nv > G) nv = G;      // trials evaluated this round
@@ -1094,33 +1279,78 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
           n_trials += w + 1;
         } else {
           n_trials += nv;
-          if (LEGACY && r0 + G >= ntrials) {
-            // every step rejected: the reference is left holding the last trial's arrays (ilqr.py:137-147)
-            win_lane = nv - 1; win_trial = ntrials;
-            new_cost = gbcast<G>(J, win_lane);
+          if (r0 + G >= ntrials) {
+            J_last = gbcast<G>(J, nv - 1);
+            if (LEGACY) {
+              // every step rejected: the reference is left holding the last trial's arrays (ilqr.py:137-147)
+              win_lane = nv - 1; win_trial = ntrials;
+              new_cost = J_last;
+            }
           }
         }
       }
+      int replay_kind = -1;                      // >= 0: the winner's trajectory has to be rolled out (again) into the spare slot
+      double replay_alpha = 0.0;
+      size_t replay_ul = 0;
       if (win_trial >= 0) {
         int ws = store_slot(win_trial);
         if (ws < 0) {
-          // an unusual winner: every lane of the group repeats its roll-out, lane 0 keeps it in the spare slot
-          __threadfence_block();
-          (void)rollout(true, (!LEGACY) || (win_trial == 1), alpha_of(win_trial), gid * G + win_lane, (gl == 0) ? SS - 1 : -1);
+          replay_kind = (LEGACY && win_trial != 1) ? 1 : 0;
+          replay_alpha = alpha_of(win_trial);
+          replay_ul = gid * G + win_lane;
           ws = SS - 1;
         }
-        cur_slot = ws; cur_par = np_;
+        cur_slot = ws;
+      } else if (NEWAL && !gate_skip) {
+        if (J_last >= old_cost) {
+          // five-wide ladder alpha, alpha/3, ... from alpha = 2^-10, smallest cost wins (new_al_ilqr.h:818-898)
+          double bestJ = 0.0, bestA = 0.0;
+          bool have = false;
+          for (int i0 = 0; i0 < 5; i0 += G) {
+            const int i = i0 + gl;
+            double al = alpha_of(ntrials + 1);
+            for (int q = 0; q < i && q < 5; ++q) al /= 3.0;
+            const double Jl = rollout(i < 5, 2, al, lg, -1);
+            for (int g = 0; g < G && i0 + g < 5; ++g) {
+              const double Jg = gbcast<G>(Jl, g), ag = gbcast<G>(al, g);
+              if (!have || Jg < bestJ) { bestJ = Jg; bestA = ag; have = true; }   // first smallest wins
+            }
+          }
+          n_trials += 5;
+          if (!(bestJ >= old_cost)) {                 // new_al_ilqr.h:1062
+            replay_kind = 0; replay_alpha = bestA; replay_ul = lg;
+            cur_slot = SS - 1;
+            win_trial = 0;
+          }
+        } else {
+          new_cost = J_last;                     // not comparable (NaN): nothing is accepted, nothing converged
+          keep_old = true;
+        }
       }
+      if (replay_kind >= 0) {
+        // every lane of the group repeats the roll-out, lane 0 keeps it in the spare slot
+        __threadfence_block();
+        const double Jr = rollout(true, replay_kind, replay_alpha, replay_ul, (gl == 0) ? SS - 1 : -1);
+        if (NEWAL && win_trial == 0) { new_cost = Jr; ++n_trials; }   // the ladder winner is re-run with the sequential arithmetic
+      }
+      if (win_trial >= 0) cur_par = np_;
       __threadfence_block();
 
       PROF_MARK(4)
       // ================= P4: inner / outer bookkeeping (ilqr.py:158-174) =================
+#ifdef ALILQR_EMU_TRACE
+      if (gl == 0 && p == 0) printf("it %d outer %d old %.17g new %.17g win %d slot %d dv %.6g gate %d keep %d trials %d\n", n_inner, outer, old_cost, new_cost, win_trial, cur_slot, dv_lin, (int)gate_skip, (int)keep_old, n_trials);
+#endif
       ++n_inner; ++inner;
-      const bool brk = fabs(new_cost - old_cost) < a.prm.inner_tol;
-      if (!brk) {
-        // x, u = new_x, new_u : the pair optimize() will return
-        for (int e = gl; e < XS; e += G) a.x_out[(size_t)p * XS + e] = *trj_at(cur_par, e, cur_slot);
-        for (int e = gl; e < US; e += G) a.u_out[(size_t)p * US + e] = *trj_at(cur_par, XS + e, cur_slot);
+      // inner stop rule: |dJ| < tol (ilqr.py:162) ; 0 <= J_old - J_new < tol (new_al_ilqr.h:1118)
+      const bool brk = NEWAL ? ((old_cost - new_cost < a.prm.inner_tol) && (old_cost - new_cost >= 0))
+                             : (fabs(new_cost - old_cost) < a.prm.inner_tol);
+      if (!brk && !keep_old) {
+        if (!NEWAL) {
+          // x, u = new_x, new_u : the pair optimize() will return (the C++ generation returns its live arrays)
+          for (int e = gl; e < XS; e += G) a.x_out[(size_t)p * XS + e] = *trj_at(cur_par, e, cur_slot);
+          for (int e = gl; e < US; e += G) a.u_out[(size_t)p * US + e] = *trj_at(cur_par, XS + e, cur_slot);
+        }
         old_cost = new_cost;
       }
       bool finished = false;
@@ -1150,7 +1380,8 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         if (viol < a.prm.viol_stop) {
           finished = true; flags = ALILQR_FLAG_VIOL_OK;
         } else {
-          if (viol >= a.prm.viol_stop && viol < a.prm.viol_lambda) {
+          // multiplier update vs penalty increase: ilqr.py:169-174 ; new_al_ilqr.h:1198-1211
+          if (NEWAL ? !(viol > a.prm.viol_lambda) : (viol >= a.prm.viol_stop && viol < a.prm.viol_lambda)) {
             for (int t = gl; t <= H; t += G) {
               double x[N], u[M];
               load_node(t, x, u);
@@ -1166,6 +1397,10 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
       }
       if (finished) {
         double fc = total_cost();
+        if (NEWAL) {
+          for (int e = gl; e < XS; e += G) a.x_out[(size_t)p * XS + e] = *trj_at(cur_par, e, cur_slot);
+          for (int e = gl; e < US; e += G) a.u_out[(size_t)p * US + e] = *trj_at(cur_par, XS + e, cur_slot);
+        }
         if (a.node_x) for (int e = gl; e < XS; e += G) a.node_x[(size_t)p * XS + e] = *trj_at(cur_par, e, cur_slot);
         if (a.node_u) for (int e = gl; e < US; e += G) a.node_u[(size_t)p * US + e] = *trj_at(cur_par, XS + e, cur_slot);
         if (a.lam)

@@ -89,3 +89,40 @@ def fast_box(B, H=50, seed=4, x0=None):
         x0 = full_start_states(B, seed)
     return desc, np.ascontiguousarray(x0, dtype=np.float64), s_curve_goals(10.0, 0.1, H, True), Q, R, \
         capi.pack_linear(A, Bm, C)
+
+
+def new_al_box(B, H=50, seed=6, x0=None, y_max=1000.0):
+    """NewALILQR<6,2> + NewBicycleNode + BoxConstraints (al_ilqr_cpp/test_new_al_ilqr.cc:117-192).
+
+    The box becomes the table the reference's BoxConstraints builds (rows [I;-I;0;0] x + [0;0;I;-I] u + C,
+    al_ilqr_cpp/constraints/box_constraints.h); y_max < 1000 makes a state bound active."""
+    A, Bm, C = box_table([-1000, -1000, -2 * np.pi, -10, -100, -10.0], [1000, y_max, 2 * np.pi, 10, 100, 10.0],
+                         [-0.2, -1.0], [0.2, 1.0])
+    desc = capi.make_problem("new_bicycle", "new_al", H, B, L=3.0, dt=0.1, v=10.0, k=0.001, c=A.shape[0])
+    desc.prm.max_outer, desc.prm.max_inner = 50, 100
+    desc.prm.viol_stop, desc.prm.viol_lambda = 1e-3, 5e-3
+    Q = np.diag([1e-1, 1e-1, 1.0, 1e-9, 1e-6, 1e-6]) * 1e3
+    R = np.eye(2) * 1e2
+    if x0 is None:
+        x0 = full_start_states(B, seed)
+    return desc, np.ascontiguousarray(x0, dtype=np.float64), s_curve_goals(10.0, 0.1, H, True), Q, R, \
+        capi.pack_linear(A, Bm, C)
+
+
+def new_al_lat(B, H=50, seed=7, x0=None):
+    """NewALILQR<4,1> + NewLatBicycleNode + a 10-row linear table of which two rows bound the
+    steering rate (al_ilqr_cpp/test_lat_al_ilqr.cc:45-95)."""
+    A = np.zeros((10, 4))
+    Bm = np.zeros((10, 1))
+    C = np.zeros(10)
+    Bm[0, 0], Bm[1, 0] = 1.0, -1.0
+    C[0] = C[1] = -0.2
+    desc = capi.make_problem("lat_k", "new_al", H, B, L=3.0, dt=0.1, v=10.0, k=0.001, c=10)
+    desc.prm.max_outer, desc.prm.max_inner = 50, 100
+    desc.prm.viol_stop, desc.prm.viol_lambda = 1e-3, 5e-3
+    Q = np.diag([1e-1, 1e-1, 1.0, 1e-9]) * 1e3
+    R = np.eye(1) * 1e2
+    if x0 is None:
+        x0 = lat_start_states(B, seed)
+    return desc, np.ascontiguousarray(x0, dtype=np.float64), s_curve_goals(10.0, 0.1, H, False), Q, R, \
+        capi.pack_linear(A, Bm, C)

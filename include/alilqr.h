@@ -28,14 +28,17 @@ extern "C" {
  * DYN      6 / 2, heading row of f_x evaluated at v      cilqr/full_bicycle_dynamic_node.py:61-108
  * DYN_MID  6 / 2, heading row of f_x evaluated at v_mid  cilqr/fast_bicycle_node.py:56-139
  *                 (same map as al_ilqr_cpp/model/new_bicycle_node.h:518-542)
- * LAT_K    4 / 1 with the (1+k v^2) understeer factor    al_ilqr_cpp/model/new_lat_bicycle_node.h:27-58
+ * LAT_K    4 / 1 with the (1+k v^2) understeer factor    al_ilqr_cpp/model/new_lat_bicycle_node.h:27-163
+ * NEW_BICYCLE 6 / 2 of the C++ generation                 al_ilqr_cpp/model/new_bicycle_node.h:228-650
+ *          (same map as DYN_MID; its f_x heading row d/dv term and its angle wrap differ)
  */
 enum alilqr_model {
   ALILQR_MODEL_LAT = 0,
   ALILQR_MODEL_KIN = 1,
   ALILQR_MODEL_DYN = 2,
   ALILQR_MODEL_DYN_MID = 3,
-  ALILQR_MODEL_LAT_K = 4
+  ALILQR_MODEL_LAT_K = 4,
+  ALILQR_MODEL_NEW_BICYCLE = 5
 };
 
 /* ---- solver generation ---------------------------------------------------
@@ -76,7 +79,7 @@ typedef struct alilqr_params {
   double quu_reg;        /* added to diag(Quu) before inversion           1e-9 / 0 / 0 */
   double alpha_min;      /* line search gives up when alpha <= this       1e-8 / 1e-8 / (10 halvings) */
   double init_r;         /* control weight of the initial-guess LQR       20 */
-  double dv_gate;        /* NEW_AL only: skip the roll-out when |dV_lin| < gate   0.2 */
+  double dv_gate;        /* NEW_AL only: skip the roll-out when |dV_lin| < gate   (double)0.2F */
 } alilqr_params;
 
 /* One batch of independent problems that share model, horizon and tables. */

@@ -81,6 +81,17 @@ int om_inv(int m, const double* Ain, double* Ainv) {
   return 0;
 }
 
+/* closed-form inverse of a 1x1 / 2x2 matrix as Eigen's fixed-size inverse() computes it */
+void or_inv_closed(int m, const double* M, double* Mi) {
+  if (m == 1) { Mi[0] = 1.0 / M[0]; return; }
+  double det = M[0] * M[3] - M[1] * M[2];
+  double invdet = 1.0 / det;
+  Mi[0] = M[3] * invdet;
+  Mi[1] = -M[1] * invdet;
+  Mi[2] = -M[2] * invdet;
+  Mi[3] = M[0] * invdet;
+}
+
 /* ------------------------------------------------------------------------ */
 /* angle wrap: (a + pi) % (2 pi) - pi with Python's floor-mod                 */
 /* cilqr/lat_bicycle_node.py:23-25                                            */

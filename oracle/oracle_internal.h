@@ -24,6 +24,7 @@ typedef struct or_node {
 void om_mm(int r, int k, int c, const double* A, const double* B, double* C);
 void om_mtm(int r, int k, int c, const double* A, const double* B, double* C);
 int om_inv(int m, const double* Ain, double* Ainv);
+void or_inv_closed(int m, const double* M, double* Mi);
 
 double or_wrap_py(double a);
 void or_node_init(or_node* nd, const alilqr_problem* p, int t,

@@ -1,0 +1,31 @@
+// Runs one problem file (written by tools/host_emu/dump_problem.py) through the kernel compiled for the host.
+#include "../../ilqr_amd/csrc/alilqr_api.hip"
+#include <vector>
+
+static std::vector<double> rd(FILE* f, size_t n) { std::vector<double> v(n); if (n && fread(v.data(), 8, n, f) != n) { perror("read"); exit(2); } return v; }
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 1;
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) { perror("open"); return 2; }
+  alilqr_problem p;
+  if (fread(&p, sizeof(p), 1, f) != 1) return 2;
+  const size_t B = p.batch, H = p.horizon, n = p.n, m = p.m, c = p.c;
+  const size_t cw = (p.mode == ALILQR_MODE_LEGACY) ? 2 * (n + m) : c * (n + m + 1);
+  auto x0 = rd(f, B * n), goals = rd(f, p.goal_batch * (H + 1) * n), Q = rd(f, p.table_nodes * n * n),
+       R = rd(f, p.table_nodes * m * m), cons = rd(f, p.table_nodes * cw);
+  std::vector<double> x(B * (H + 1) * n), u(B * H * m), nx(x.size()), nu(u.size()), xi(x.size()), ui(u.size()),
+      cost(B), viol(B), lam(B * (H + 1) * c), mu(B);
+  std::vector<int32_t> st(B * 4);
+  int rc = alilqr_solve_batch(&p, x0.data(), goals.data(), Q.data(), R.data(), cons.data(), x.data(), u.data(), nx.data(), nu.data(),
+                              xi.data(), ui.data(), cost.data(), viol.data(), lam.data(), mu.data(), st.data(), nullptr);
+  printf("rc %d %s\n", rc, alilqr_last_error());
+  for (size_t b = 0; b < B; ++b) printf("[%zu] cost %.12g viol %.3e mu %g status %d %d %d %d\n", b, cost[b], viol[b], mu[b], st[4 * b], st[4 * b + 1], st[4 * b + 2], st[4 * b + 3]);
+  if (argc > 2) {
+    FILE* o = fopen(argv[2], "wb");
+    fwrite(x.data(), 8, x.size(), o); fwrite(u.data(), 8, u.size(), o); fwrite(cost.data(), 8, B, o); fwrite(st.data(), 4, st.size(), o);
+    fclose(o);
+  }
+  alilqr_release();
+  return 0;
+}

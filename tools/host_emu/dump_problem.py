@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Write one synthetic problem set as the flat file tools/host_emu/driver.cpp reads: descriptor, x0, goals, Q, R, cons."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from ilqr_amd import problems
+
+def main():
+    name, B, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    sets = {"new_box": lambda: problems.new_al_box(B), "new_lat": lambda: problems.new_al_lat(B),
+            "new_box_active": lambda: problems.new_al_box(B, y_max=20.0),
+            "lat_legacy": lambda: problems.lat_legacy(B), "fast_box": lambda: problems.fast_box(B),
+            "dyn_legacy": lambda: problems.full_legacy("dyn", B, 60, 3)}
+    desc, x0, goals, Q, R, cons = sets[name]()
+    with open(out, "wb") as f:
+        f.write(bytes(desc))
+        for a in (x0, goals, Q, R, cons):
+            f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+
+if __name__ == "__main__":
+    main()
