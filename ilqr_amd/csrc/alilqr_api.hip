@@ -73,7 +73,6 @@ int32_t check_problem(const alilqr_problem* p, Dims* d) {
     if (p->c < 1 || p->c > 64) { set_err("FAST needs 1 <= c <= 64"); return ALILQR_E_ARG; }
     if (p->model != ALILQR_MODEL_DYN_MID) { set_err("FAST is defined for DYN_MID"); return ALILQR_E_ARG; }
   } else if (p->mode == ALILQR_MODE_NEW_AL) {
-    if (!std::getenv("ALILQR_ENABLE_NEW_AL")) { set_err("NEW_AL is not enabled in this build"); return ALILQR_E_ARG; }
     if (p->c < 1 || p->c > 64) { set_err("NEW_AL needs 1 <= c <= 64"); return ALILQR_E_ARG; }
     if (p->model != ALILQR_MODEL_LAT_K && p->model != ALILQR_MODEL_NEW_BICYCLE) {
       set_err("NEW_AL is defined for LAT_K, NEW_BICYCLE"); return ALILQR_E_ARG;

@@ -1060,26 +1060,43 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
       PROF_MARK(2)
       // ================= P2: backward Riccati sweep =================
       {
-        struct LinRegs { double v[NR::E]; };
+        // Registers of one linearisation record.  The part needed first (f_x, f_u, l_x, l_u) is loaded one step
+        // ahead into a second buffer; the second-order part (l_xx, l_uu, f_xx), needed late in a step, is loaded
+        // at the top of its own step and lands while the first products are computed.  LEGACY records are
+        // short (diagonal second-order part) and are loaded ahead whole.
+        constexpr int EA = LEGACY ? NR::E : NR::oHx;
+        struct LinRegs { double v[EA]; };
+        struct LinLate { double v[NR::E - EA + 1]; };
         auto load_lin = [&](int t, LinRegs& L) {
           const double* lr = lrec(t);
 #pragma unroll
-          for (int i = 0; i < NR::E; ++i) L.v[i] = lr[(size_t)i * ES];
+          for (int i = 0; i < EA; ++i) L.v[i] = lr[(size_t)i * ES];
+        };
+        auto load_late = [&](int t, LinLate& Lt) {
+          const double* lr = lrec(t);
+#pragma unroll
+          for (int i = EA; i < NR::E; ++i) Lt.v[i - EA] = lr[(size_t)i * ES];
         };
         double Vx[N], Vxx[N][N];
         {
           LinRegs LH;
+          LinLate LHt;
           load_lin(H, LH);
+          load_late(H, LHt);
           ctab Q = tabQ(H);
 #pragma unroll
           for (int i = 0; i < N; ++i) {
             Vx[i] = LH.v[NR::oLx + i];
 #pragma unroll
-            for (int j = 0; j < N; ++j)
-              Vxx[i][j] = LEGACY ? ((i == j) ? LH.v[NR::oHx + i] : 2 * Q[i * N + j]) : LH.v[NR::oHx + i * N + j];
+            for (int j = 0; j < N; ++j) {
+              if constexpr (LEGACY) Vxx[i][j] = (i == j) ? LH.v[NR::oHx + i] : 2 * Q[i * N + j];
+              else Vxx[i][j] = LHt.v[NR::oHx - EA + i * N + j];
+            }
           }
         }
         auto sweep = [&](int t, const LinRegs& L, LinRegs& Lnext) {
+          LinLate Lt;
+          if (!LEGACY) load_late(t, Lt);
           if (t > 0) load_lin(t - 1, Lnext);            // in flight while this step computes
           double S[N][N], Bm[N][M], K[M][N], kf[M], dl;
           expand_jac<MD>(mc, &L.v[NR::oA], &L.v[NR::oB], S, Bm);
@@ -1088,9 +1105,17 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
           riccati_step<MD>(S, Bm,
                            [&](int i) { return L.v[NR::oLx + i]; },
                            [&](int r) { return L.v[NR::oLu + r]; },
-                           [&](int i, int j) { return LEGACY ? ((i == j) ? L.v[NR::oHx + i] : 2 * Q[i * N + j]) : L.v[NR::oHx + i * N + j]; },
-                           [&](int r, int b) { return LEGACY ? ((r == b) ? L.v[NR::oHu + r] : 2 * R[r * M + b]) : L.v[NR::oHu + r * M + b]; },
-                           [&](double acc, int i, int j, const double* Vo) { return FxxOf<MD, NEWAL>::add(acc, &L.v[NR::oF], Vo, i, j); },
+                           [&](int i, int j) {
+                             if constexpr (LEGACY) return (i == j) ? L.v[NR::oHx + i] : 2 * Q[i * N + j];
+                             else return Lt.v[NR::oHx - EA + i * N + j];
+                           },
+                           [&](int r, int b) {
+                             if constexpr (LEGACY) return (r == b) ? L.v[NR::oHu + r] : 2 * R[r * M + b];
+                             else return Lt.v[NR::oHu - EA + r * M + b];
+                           },
+                           [&](double acc, int i, int j, const double* Vo) {
+                             return FxxOf<MD, NEWAL>::add(acc, &Lt.v[NEWAL ? NR::oF - EA : 0], Vo, i, j);
+                           },
                            a.prm.quu_reg, &dl, Vx, Vxx, K, kf);
           dv_lin += dl;
           if (gl == 0) {
@@ -1243,95 +1268,128 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
       int win_trial = -1, win_lane = -1;
       double J_last = 0.0;
       const bool gate_skip = NEWAL && (fabs(dv_lin) < a.prm.dv_gate);      // new_al_ilqr.h:1039
-      for (int r0 = 0; r0 < ntrials && win_trial < 0 && !gate_skip; r0 += G) {
-        const int j = r0 + gl + 1;              // trial number, 1-based
-        const bool valid = j <= ntrials;
-        const int kind = (LEGACY && j != 1) ? 1 : 0;  // LEGACY trials >= 2 run open loop on accumulated controls
-        if (LEGACY) {
-          // Accumulated controls of the open-loop trials of this round, nodes in parallel:
-          //   u_i = u_{i-1} + 2^-(i-1) k   (ilqr.py:119 with new_u aliasing u); lane i-1-r0 rolls u_i out.
-          const int first = (r0 == 0) ? 2 : r0 + 1;
-          const int last = (r0 + G < ntrials) ? r0 + G : ntrials;
-          const bool from_cur = (r0 == 0) || (G == 1 && r0 == 1);
-          for (int t = gl; t < H && first <= last; t += G) {
-            const double* rt = rec(t);
+      // The passes of the line search (rounds of trials, the C++ generation's ladder, the repeat of a winner
+      // whose trajectory was not kept) go through ONE roll-out call: the groups of a wave that are in
+      // different passes still execute it together, and the roll-out code exists once.
+      enum { ST_TRIALS = 0, ST_LADDER = 1, ST_REPLAY = 2, ST_DONE = 3 };
+      int stage = gate_skip ? ST_DONE : ST_TRIALS;
+      int r0 = 0;                                // first trial of the current round, or first ladder column
+      int replay_kind = 0;
+      double replay_alpha = 0.0, bestJ = 0.0, bestA = 0.0;
+      size_t replay_ul = 0;
+      bool have = false;
+      while (stage != ST_DONE) {
+        bool valid = true;
+        int kind = 0, sslot = -1;
+        double alpha = 1.0;
+        size_t ul = lg;
+        if (stage == ST_TRIALS) {
+          const int j = r0 + gl + 1;             // trial number, 1-based
+          valid = j <= ntrials;
+          kind = (LEGACY && j != 1) ? 1 : 0;     // LEGACY trials >= 2 run open loop on accumulated controls
+          alpha = alpha_of(j);
+          sslot = valid ? store_slot(j) : -1;
+          if (LEGACY) {
+            // Accumulated controls of the open-loop trials of this round, nodes in parallel:
+            //   u_i = u_{i-1} + 2^-(i-1) k   (ilqr.py:119 with new_u aliasing u); lane i-1-r0 rolls u_i out.
+            const int first = (r0 == 0) ? 2 : r0 + 1;
+            const int last = (r0 + G < ntrials) ? r0 + G : ntrials;
+            const bool from_cur = (r0 == 0) || (G == 1 && r0 == 1);
+            for (int t = gl; t < H && first <= last; t += G) {
+              const double* rt = rec(t);
 #pragma unroll
-            for (int r = 0; r < M; ++r) {
-              const double kf = rt[(size_t)(RL::rk + r) * ES];
-              double s = from_cur ? rt[(size_t)(RL::ru + r) * ES] : *ucum_at(t * M + r, gid * G + (G - 1));
-              double al = alpha_of(first);
-              for (int i = first; i <= last; ++i) {
-                s = s + al * kf;
-                al = al / 2.0;
-                *ucum_at(t * M + r, gid * G + (i - 1 - r0)) = s;
+              for (int r = 0; r < M; ++r) {
+                const double kf = rt[(size_t)(RL::rk + r) * ES];
+                double sacc = from_cur ? rt[(size_t)(RL::ru + r) * ES] : *ucum_at(t * M + r, gid * G + (G - 1));
+                double al = alpha_of(first);
+                for (int i = first; i <= last; ++i) {
+                  sacc = sacc + al * kf;
+                  al = al / 2.0;
+                  *ucum_at(t * M + r, gid * G + (i - 1 - r0)) = sacc;
+                }
               }
             }
           }
-          __threadfence_block();
-        }
-        const double J = rollout(valid, kind, alpha_of(j), lg, valid ? store_slot(j) : -1);
-        const bool ok = valid && (J < old_cost);
-        int w = gfirst<G>(ok, lane);
-        int nv = ntrials - r0; if (nv > G) nv = G;      // trials evaluated this round
-        if (w >= 0) {
-          win_lane = w; win_trial = r0 + w + 1;
-          new_cost = gbcast<G>(J, w);
-          n_trials += w + 1;
+        } else if (stage == ST_LADDER) {
+          // five-wide ladder alpha, alpha/3, ... from alpha = 2^-10 (new_al_ilqr.h:818-898)
+          const int i = r0 + gl;
+          valid = i < 5;
+          kind = 2;
+          alpha = alpha_of(ntrials + 1);
+          for (int q = 0; q < i && q < 5; ++q) alpha /= 3.0;
         } else {
-          n_trials += nv;
-          if (r0 + G >= ntrials) {
-            J_last = gbcast<G>(J, nv - 1);
-            if (LEGACY) {
-              // every step rejected: the reference is left holding the last trial's arrays (ilqr.py:137-147)
-              win_lane = nv - 1; win_trial = ntrials;
-              new_cost = J_last;
-            }
-          }
+          // every lane of the group repeats the winner's roll-out, lane 0 keeps it in the spare slot
+          kind = replay_kind; alpha = replay_alpha; ul = replay_ul;
+          sslot = (gl == 0) ? SS - 1 : -1;
         }
-      }
-      int replay_kind = -1;                      // >= 0: the winner's trajectory has to be rolled out (again) into the spare slot
-      double replay_alpha = 0.0;
-      size_t replay_ul = 0;
-      if (win_trial >= 0) {
-        int ws = store_slot(win_trial);
-        if (ws < 0) {
-          replay_kind = (LEGACY && win_trial != 1) ? 1 : 0;
-          replay_alpha = alpha_of(win_trial);
-          replay_ul = gid * G + win_lane;
-          ws = SS - 1;
-        }
-        cur_slot = ws;
-      } else if (NEWAL && !gate_skip) {
-        if (J_last >= old_cost) {
-          // five-wide ladder alpha, alpha/3, ... from alpha = 2^-10, smallest cost wins (new_al_ilqr.h:818-898)
-          double bestJ = 0.0, bestA = 0.0;
-          bool have = false;
-          for (int i0 = 0; i0 < 5; i0 += G) {
-            const int i = i0 + gl;
-            double al = alpha_of(ntrials + 1);
-            for (int q = 0; q < i && q < 5; ++q) al /= 3.0;
-            const double Jl = rollout(i < 5, 2, al, lg, -1);
-            for (int g = 0; g < G && i0 + g < 5; ++g) {
-              const double Jg = gbcast<G>(Jl, g), ag = gbcast<G>(al, g);
-              if (!have || Jg < bestJ) { bestJ = Jg; bestA = ag; have = true; }   // first smallest wins
-            }
-          }
-          n_trials += 5;
-          if (!(bestJ >= old_cost)) {                 // new_al_ilqr.h:1062
-            replay_kind = 0; replay_alpha = bestA; replay_ul = lg;
-            cur_slot = SS - 1;
-            win_trial = 0;
-          }
-        } else {
-          new_cost = J_last;                     // not comparable (NaN): nothing is accepted, nothing converged
-          keep_old = true;
-        }
-      }
-      if (replay_kind >= 0) {
-        // every lane of the group repeats the roll-out, lane 0 keeps it in the spare slot
         __threadfence_block();
-        const double Jr = rollout(true, replay_kind, replay_alpha, replay_ul, (gl == 0) ? SS - 1 : -1);
-        if (NEWAL && win_trial == 0) { new_cost = Jr; ++n_trials; }   // the ladder winner is re-run with the sequential arithmetic
+        const double J = rollout(valid, kind, alpha, ul, sslot);
+
+        if (stage == ST_TRIALS) {
+          const bool ok = valid && (J < old_cost);
+          const int w = gfirst<G>(ok, lane);
+          int nv = ntrials - r0; if (nv > G) nv = G;      // trials evaluated this round
+          if (w >= 0) {
+            win_lane = w; win_trial = r0 + w + 1;
+            new_cost = gbcast<G>(J, w);
+            n_trials += w + 1;
+          } else {
+            n_trials += nv;
+            if (r0 + G >= ntrials) {
+              J_last = gbcast<G>(J, nv - 1);
+              if (LEGACY) {
+                // every step rejected: the reference is left holding the last trial's arrays (ilqr.py:137-147)
+                win_lane = nv - 1; win_trial = ntrials;
+                new_cost = J_last;
+              }
+            }
+          }
+          if (win_trial >= 0) {
+            const int ws = store_slot(win_trial);
+            if (ws < 0) {
+              replay_kind = (LEGACY && win_trial != 1) ? 1 : 0;
+              replay_alpha = alpha_of(win_trial);
+              replay_ul = gid * G + win_lane;
+              cur_slot = SS - 1;
+              stage = ST_REPLAY;
+            } else {
+              cur_slot = ws;
+              stage = ST_DONE;
+            }
+          } else if (r0 + G < ntrials) {
+            r0 += G;                             // next round of trials
+          } else if (NEWAL) {
+            if (J_last >= old_cost) {
+              stage = ST_LADDER; r0 = 0; have = false;
+            } else {
+              new_cost = J_last;                 // not comparable (NaN): nothing is accepted, nothing converged
+              keep_old = true;
+              stage = ST_DONE;
+            }
+          } else {
+            stage = ST_DONE;
+          }
+        } else if (stage == ST_LADDER) {
+          for (int g = 0; g < G && r0 + g < 5; ++g) {
+            const double Jg = gbcast<G>(J, g), ag = gbcast<G>(alpha, g);
+            if (!have || Jg < bestJ) { bestJ = Jg; bestA = ag; have = true; }   // first smallest wins
+          }
+          r0 += G;
+          if (r0 >= 5) {
+            n_trials += 5;
+            if (!(bestJ >= old_cost)) {          // new_al_ilqr.h:1062
+              replay_kind = 0; replay_alpha = bestA; replay_ul = lg;
+              cur_slot = SS - 1;
+              win_trial = 0;
+              stage = ST_REPLAY;
+            } else {
+              stage = ST_DONE;
+            }
+          }
+        } else {
+          if (NEWAL && win_trial == 0) { new_cost = J; ++n_trials; }   // the ladder winner is re-run with the sequential arithmetic
+          stage = ST_DONE;
+        }
       }
       if (win_trial >= 0) cur_par = np_;
       __threadfence_block();

@@ -1,0 +1,110 @@
+"""CPU checks of the C++-generation (NewALILQR) oracle.
+
+PARITY UNPINNED: the C++ reference cannot be built in this image (it needs Eigen, which is absent) and ships
+no output vectors, so nothing here compares a full solve with the reference's own numbers.  What can be
+anchored is anchored: the node formulas the C++ generation shares with the Python FastBicycleNode are checked
+against that node's golden vectors, and the solver is checked on the reference's own demo configurations
+(al_ilqr_cpp/test_new_al_ilqr.cc:117-192, test_lat_al_ilqr.cc:45-95) for the behaviour those programs show:
+convergence below the violation tolerance with a finite cost.
+"""
+import numpy as np
+
+import golden_util as gu
+import oracle_lib as ol
+from ilqr_amd import capi, problems
+
+
+def test_new_bicycle_node_shares_the_fast_node_formulas():
+    """f, f_u, f_x (all rows but the d(heading)/dv entry, which the C++ file writes differently:
+    new_bicycle_node.h:518-542 vs fast_bicycle_node.py:56-139), cost, l_x, l_u, l_xx, l_uu, constraint values and
+    the multiplier update, at the FastBicycleNode golden points whose angles need no wrap."""
+    k = gu.load("nodes_kat")
+    pre = "fast_box_"
+    X, U, LAM, MU = k[pre + "X"], k[pre + "U"], k[pre + "LAM"], k[pre + "MU"]
+    keep = (np.abs(X[:, 2]) < 3.0) & (np.abs(X[:, 3]) < 3.0)
+    assert keep.sum() >= 8
+    X, U, LAM, MU = X[keep], U[keep], LAM[keep], MU[keep]
+    N = X.shape[0]
+    Q = k[pre + "Q"]
+    assert np.count_nonzero(Q - np.diag(np.diag(Q))) == 0      # the C++ cost reads diag(Q) only
+    cons = capi.pack_linear(k[pre + "A"], k[pre + "B"], k[pre + "C"])
+    desc = capi.make_problem("new_bicycle", "new_al", 1, N, float(k[pre + "L"]), float(k[pre + "dt"]),
+                             k=float(k[pre + "k"]), c=k[pre + "A"].shape[0])
+    goals = np.tile(k[pre + "goal"], (2, 1))
+    x = np.zeros((N, 2, 6)); x[:, 0] = X
+    u = np.zeros((N, 2, 2)); u[:, 0] = U
+    lam = np.zeros((N, 2, desc.c)); lam[:, 0] = LAM
+    out = ol.linearize_batch(desc, x, u, lam, MU, goals, Q, k[pre + "R"], cons)
+    for key, okey in (("f", "f"), ("fu", "fu"), ("l", "l"), ("lx", "lx"), ("lu", "lu"),
+                      ("lxx", "lxx"), ("luu", "luu"), ("cons", "cval"), ("lam_new", "lam_new")):
+        assert gu.rel_err(out[okey][:, 0], k[pre + key][keep]) < 1e-12, key
+    fx, ref = out["fx"][:, 0].copy(), k[pre + "fx"][keep].copy()
+    assert np.abs(fx[:, 2, 4] - ref[:, 2, 4]).max() > 0       # the one entry the two generations disagree on
+    fx[:, 2, 4] = ref[:, 2, 4] = 0.0
+    assert gu.rel_err(fx, ref) < 1e-12
+
+
+def test_float_literal_gate():
+    """|dV_lin| is compared with the float literal 0.2F (new_al_ilqr.h:1039), not with 0.2."""
+    prm = capi.default_params("new_al")
+    assert prm.dv_gate == float(np.float32(0.2)) and prm.dv_gate != 0.2
+
+
+def _demo(desc, x0, goals, Q, R, cons):
+    return ol.solve_traced(desc, x0, goals, Q, R, cons)
+
+
+def test_reference_demo_full_model_converges():
+    """al_ilqr_cpp/test_new_al_ilqr.cc:117-192: start (0,0,0,0,v,0), optimize(50, 100, 1e-3)."""
+    desc, _, goals, Q, R, cons = problems.new_al_box(1)
+    x0 = np.array([[0.0, 0.0, 0.0, 0.0, 10.0, 0.0]])
+    out = _demo(desc, x0, goals, Q, R, cons)
+    assert out["status"][0, 2] == capi.FLAG_VIOL_OK
+    assert out["viol"][0] < 1e-3 and np.isfinite(out["cost"][0])
+    assert np.all(np.abs(out["u"][0, :, 0]) <= 0.2 + 1e-3) and np.all(np.abs(out["u"][0, :, 1]) <= 1.0 + 1e-3)
+    ic = out["iter_cost"]
+    assert ic.size == out["status"][0, 0]
+    # the trajectory tracks the S-curve (it starts with a heading error of 0.46 rad and a rate-limited steering)
+    assert np.abs(out["x"][0, :, :2] - goals[:, :2]).mean() < 2.0
+
+
+def test_reference_demo_lateral_model_converges():
+    """al_ilqr_cpp/test_lat_al_ilqr.cc:45-95: start (0,0,0,0), ten-row table with two live rows."""
+    desc, _, goals, Q, R, cons = problems.new_al_lat(1)
+    out = _demo(desc, np.zeros((1, 4)), goals, Q, R, cons)
+    assert out["status"][0, 2] == capi.FLAG_VIOL_OK
+    assert out["viol"][0] < 1e-3 and np.isfinite(out["cost"][0])
+    assert np.all(np.abs(out["u"][0, :, 0]) <= 0.2 + 1e-3)
+
+
+def test_returned_trajectory_is_a_rollout_of_the_returned_controls():
+    """get_x_list()/get_u_list() are the live arrays: x_{t+1} = f(x_t, u_t) holds exactly on them."""
+    desc, x0, goals, Q, R, cons = problems.new_al_box(3, H=30, seed=9)
+    out = ol.solve_batch(desc, x0, goals, Q, R, cons)
+    B, H = 3, 30
+    ld = capi.make_problem("new_bicycle", "new_al", H, B, desc.L, desc.dt, k=desc.k, c=desc.c)
+    u_pad = np.concatenate([out["u"], np.zeros((B, 1, 2))], axis=1)
+    lin = ol.linearize_batch(ld, out["x"], u_pad, np.zeros((B, H + 1, desc.c)), np.ones(B), goals, Q, R, cons)
+    assert np.array_equal(lin["f"][:, :-1], out["x"][:, 1:])
+    assert np.array_equal(out["x"][:, 0], x0)
+
+
+def test_new_lat_node_with_zero_understeer_is_the_python_lateral_model():
+    """With k = 0 the factor (1 + k v^2) is exactly 1 and new_lat_bicycle_node.h:27-126 must give the
+    dynamics and Jacobians of cilqr/lat_bicycle_node.py:32-91 (golden points whose angles need no wrap)."""
+    k = gu.load("nodes_kat")
+    pre = "legacy_lat_"
+    X, U = k[pre + "X"], k[pre + "U"]
+    keep = (np.abs(X[:, 2]) < 3.0) & (np.abs(X[:, 3]) < 3.0)
+    assert keep.sum() >= 8
+    X, U = X[keep], U[keep]
+    N = X.shape[0]
+    A = np.zeros((2, 4)); Bm = np.array([[1.0], [-1.0]]); Cv = np.array([-0.2, -0.2])
+    desc = capi.make_problem("lat_k", "new_al", 1, N, float(k[pre + "L"]), float(k[pre + "dt"]), v=float(k[pre + "v"]),
+                             k=0.0, c=2)
+    x = np.zeros((N, 2, 4)); x[:, 0] = X
+    u = np.zeros((N, 2, 1)); u[:, 0] = U
+    out = ol.linearize_batch(desc, x, u, np.zeros((N, 2, 2)), np.ones(N), np.zeros((2, 4)), k[pre + "Q"], k[pre + "R"],
+                             capi.pack_linear(A, Bm, Cv))
+    for key in ("f", "fx", "fu"):
+        assert gu.rel_err(out[key][:, 0], k[pre + key][keep]) < 1e-12, key

@@ -16,7 +16,10 @@ def main():
     cpu_only = "--cpu" in sys.argv
     if not cpu_only:
         from ilqr_amd import batch
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
     for name, (desc, x0, goals, Q, R, cons) in sets(B).items():
+        if only and name not in only:
+            continue
         t = time.time()
         ref = ol.solve_batch(desc, x0, goals, Q, R, cons)
         tc = time.time() - t
