@@ -101,7 +101,8 @@ _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libalilqr_hip.so")
 
 EXPORTS = ("alilqr_abi_version", "alilqr_last_error", "alilqr_device_count", "alilqr_default_params",
-           "alilqr_workspace_bytes", "alilqr_solve_batch", "alilqr_linearize_batch", "alilqr_release")
+           "alilqr_workspace_bytes", "alilqr_solve_batch", "alilqr_solve_batch_multistart", "alilqr_linearize_batch",
+           "alilqr_release")
 
 
 class LibraryMissing(RuntimeError):
@@ -132,6 +133,8 @@ def load_library():
     lib.alilqr_workspace_bytes.argtypes = [C.POINTER(Problem)]
     lib.alilqr_solve_batch.restype = C.c_int32
     lib.alilqr_solve_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17
+    lib.alilqr_solve_batch_multistart.restype = C.c_int32
+    lib.alilqr_solve_batch_multistart.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 18
     lib.alilqr_linearize_batch.restype = C.c_int32
     lib.alilqr_linearize_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17
     lib.alilqr_release.restype = C.c_int32

@@ -272,6 +272,20 @@ int32_t alilqr_solve_batch(const alilqr_problem* p,
                            double* cost, double* viol,
                            double* lam, double* mu,
                            int32_t* status, void* stream) {
+  return alilqr_solve_batch_multistart(p, x0, goals, Q, R, cons, nullptr, x_out, u_out, node_x, node_u, x_init, u_init,
+                                       cost, viol, lam, mu, status, stream);
+}
+
+int32_t alilqr_solve_batch_multistart(const alilqr_problem* p,
+                                      const double* x0, const double* goals,
+                                      const double* Q, const double* R, const double* cons,
+                                      const double* u_offset,
+                                      double* x_out, double* u_out,
+                                      double* node_x, double* node_u,
+                                      double* x_init, double* u_init,
+                                      double* cost, double* viol,
+                                      double* lam, double* mu,
+                                      int32_t* status, void* stream) {
   Dims d;
   int32_t rc = check_problem(p, &d);
   if (rc != ALILQR_OK) return rc;
@@ -308,7 +322,7 @@ int32_t alilqr_solve_batch(const alilqr_problem* p,
   ka.goal_batch = p->goal_batch; ka.table_nodes = p->table_nodes;
   ka.mc = {p->L, p->dt, p->v, p->k};
   ka.prm = p->prm;
-  ka.x0 = x0; ka.goals = goals; ka.Q = Q; ka.R = R; ka.cons = cons;
+  ka.x0 = x0; ka.goals = goals; ka.Q = Q; ka.R = R; ka.cons = cons; ka.u_off = u_offset;
   ka.x_out = x_out; ka.u_out = u_out; ka.node_x = node_x; ka.node_u = node_u;
   ka.x_init = x_init; ka.u_init = u_init; ka.cost = cost; ka.viol = viol; ka.lam = lam; ka.mu = mu;
   ka.status = status;

@@ -65,6 +65,7 @@ struct KArgs {
   ModelConst mc;
   alilqr_params prm;
   const double *x0, *goals, *Q, *R, *cons;
+  const double* u_off;        // optional [B][H][m] added to the controls of the initial guess (multi-start), or null
   double *x_out, *u_out, *node_x, *node_u, *x_init, *u_init, *cost, *viol, *lam, *mu;
   int32_t* status;
   double *trj, *blk, *ucum;
@@ -963,6 +964,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
               double acc = 0.0;
 #pragma unroll
               for (int i = 0; i < N; ++i) acc += (-rt[(size_t)(RL::rK + r * N + i) * ES]) * (x[i] - goals[(size_t)t * N + i]);
+              if (a.u_off) acc = acc + a.u_off[(size_t)p * US + t * M + r];
               u[r] = acc;
             }
             MD::template step<false>(mc, x, u, xn);

@@ -126,3 +126,51 @@ def new_al_lat(B, H=50, seed=7, x0=None):
         x0 = lat_start_states(B, seed)
     return desc, np.ascontiguousarray(x0, dtype=np.float64), s_curve_goals(10.0, 0.1, H, False), Q, R, \
         capi.pack_linear(A, Bm, C)
+
+
+def multi_start(scenarios, starts, H=50, seed=3, sigma=0.02):
+    """`starts` starts for each of `scenarios` lateral problems: every start of a scenario has the scenario's
+    start state and the controls of its initial guess moved by sigma * N(0,1); start 0 of each scenario is the
+    unperturbed one.  Problem index = scenario * starts + start.  Solved with the C++ generation's line search."""
+    rng = np.random.default_rng(seed)
+    B = scenarios * starts
+    desc, _, goals, Q, R, cons = new_al_lat(B, H=H)
+    x0 = np.repeat(lat_start_states(scenarios, seed), starts, axis=0)
+    u_offset = sigma * rng.standard_normal((scenarios, starts, H, 1))
+    u_offset[:, 0] = 0.0
+    return desc, np.ascontiguousarray(x0), goals, Q, R, cons, np.ascontiguousarray(u_offset.reshape(B, H, 1))
+
+
+def kin_linear(B, H=50, seed=1, y_max=23.5):
+    """Kinematic 6/2 model (k = 0) with a static linear table: the four control-bound rows, a half-plane
+    y <= y_max, a half-plane y >= -y_max and two spare all-zero rows (the row pool the reference keeps for
+    rows it activates later, linear_constraints.h:360-373).  C++-generation solver, weights of
+    al_ilqr_cpp/test_new_al_ilqr.cc:127-137, start states (0, U(-1,1), U(-0.1,0.1), 0, 10+U(-1,1), 0)."""
+    c = 8
+    A = np.zeros((c, 6)); Bm = np.zeros((c, 2)); C = np.zeros(c)
+    Bm[0, 0], C[0] = 1.0, -0.2
+    Bm[1, 0], C[1] = -1.0, -0.2
+    Bm[2, 1], C[2] = 1.0, -1.0
+    Bm[3, 1], C[3] = -1.0, -1.0
+    A[4, 1], C[4] = 1.0, -y_max
+    A[5, 1], C[5] = -1.0, -y_max
+    desc = capi.make_problem("new_bicycle", "new_al", H, B, L=3.0, dt=0.1, v=10.0, k=0.0, c=c)
+    desc.prm.max_outer, desc.prm.max_inner = 50, 100
+    desc.prm.viol_stop, desc.prm.viol_lambda = 1e-3, 5e-3
+    Q = np.diag([1e-1, 1e-1, 1.0, 1e-9, 1e-6, 1e-6]) * 1e3
+    R = np.eye(2) * 1e2
+    return desc, full_start_states(B, seed), s_curve_goals(10.0, 0.1, H, True), Q, R, capi.pack_linear(A, Bm, C)
+
+
+def fast_box_linear(B, H=100, seed=2):
+    """FastILQR + FastBicycleNode with the box of cilqr/test_fast_full.py:31-60 stacked with two extra
+    half-plane rows (y <= 40, active near the crest of the S-curve, and y >= -5): a linear table of 18 rows."""
+    A, Bm, C = box_table([-1000, -1000, -2 * np.pi, -10, -100, -10.0], [1000, 1000, 2 * np.pi, 10, 100, 10.0],
+                         [-0.2, -1.0], [0.2, 1.0])
+    A = np.vstack([A, [[0, 1.0, 0, 0, 0, 0], [0, -1.0, 0, 0, 0, 0]]])
+    Bm = np.vstack([Bm, np.zeros((2, 2))])
+    C = np.concatenate([C, [-40.0, -5.0]])
+    desc = capi.make_problem("dyn_mid", "fast", H, B, L=1.0, dt=0.1, v=10.0, k=0.001, c=A.shape[0])
+    Q = np.diag([1e-1, 1e-1, 1.0, 1e-9, 1e-6, 1e-6]) * 1e3
+    R = np.eye(2) * 1e2
+    return desc, full_start_states(B, seed), s_curve_goals(10.0, 0.1, H, True), Q, R, capi.pack_linear(A, Bm, C)

@@ -152,6 +152,26 @@ int32_t alilqr_solve_batch(const alilqr_problem* p,
                            int32_t* status, void* stream);
 
 /*
+ * Multi-start variant of alilqr_solve_batch: u_offset [B][H][m] (device pointer, may be NULL) is added to the
+ * controls of the linearised-LQR initial guess while it is rolled out,
+ *     u_t = -K_t (x_t - goal_t) + u_offset_t ,  x_{t+1} = f(x_t, u_t)
+ * (the roll-out of cilqr/ilqr.py:41-47, cilqr/fast_ilqr.py:40-46, al_ilqr_cpp/new_al_ilqr.h:679-690 with a
+ * perturbed control), so that the B problems can be B different starts of the same scenario.  The reference has
+ * no multi-start driver; everything after the initial guess is alilqr_solve_batch unchanged, and with
+ * u_offset == NULL the two calls are the same call.
+ */
+int32_t alilqr_solve_batch_multistart(const alilqr_problem* p,
+                                      const double* x0, const double* goals,
+                                      const double* Q, const double* R, const double* cons,
+                                      const double* u_offset,
+                                      double* x_out, double* u_out,
+                                      double* node_x, double* node_u,
+                                      double* x_init, double* u_init,
+                                      double* cost, double* viol,
+                                      double* lam, double* mu,
+                                      int32_t* status, void* stream);
+
+/*
  * Parallel-in-time linearisation / quadratisation of N = B*(H+1) independent
  * (node, state, control) points: the per-node calls the reference makes at
  * the top of its backward pass (cilqr/ilqr.py:70-77, cilqr/fast_ilqr.py:69-76):

@@ -497,6 +497,8 @@ static double compute_total_cost(py_solver* s) {           /* ilqr.py:52-56 */
   return total;
 }
 
+_Thread_local const double* or_u_offset = NULL;
+
 /* ilqr.py:11-50 / fast_ilqr.py:10-49 */
 static void linearized_initial_guess(py_solver* s, double* x, double* u) {
   int H = s->H, n = s->n, m = s->m;
@@ -536,6 +538,7 @@ static void linearized_initial_guess(py_solver* s, double* x, double* u) {
     for (int j = 0; j < m; ++j) {
       double acc = 0.0;
       for (int i = 0; i < n; ++i) acc += (-K[j * n + i]) * d[i];
+      if (or_u_offset) acc = acc + or_u_offset[t * m + j];
       u[t * m + j] = acc;
     }
     or_py_dynamics(nd, x + t * n, u + t * m, x + (t + 1) * n);
@@ -802,9 +805,9 @@ int32_t oracle_max_threads(void) {
 #endif
 }
 
-int32_t oracle_solve_batch(const alilqr_problem* p,
+int32_t oracle_solve_batch_multistart(const alilqr_problem* p,
                            const double* x0, const double* goals,
-                           const double* Q, const double* R, const double* cons,
+                           const double* Q, const double* R, const double* cons, const double* u_offset,
                            double* x_out, double* u_out, double* node_x, double* node_u,
                            double* x_init, double* u_init, double* cost, double* viol,
                            double* lam, double* mu, int32_t* status, int32_t threads) {
@@ -818,6 +821,7 @@ int32_t oracle_solve_batch(const alilqr_problem* p,
 #endif
   for (int b = 0; b < B; ++b) {
     const double* g = goals + ((p->goal_batch > 1) ? (size_t)b * xs : 0);
+    or_u_offset = u_offset ? u_offset + (size_t)b * us : NULL;
     int r = oracle_solve(p, x0 + (size_t)b * n, g, Q, R, cons,
                          x_out ? x_out + b * xs : NULL, u_out ? u_out + b * us : NULL,
                          node_x ? node_x + b * xs : NULL, node_u ? node_u + b * us : NULL,
@@ -825,10 +829,21 @@ int32_t oracle_solve_batch(const alilqr_problem* p,
                          cost ? cost + b : NULL, viol ? viol + b : NULL,
                          lam ? lam + b * ls : NULL, mu ? mu + b : NULL,
                          status ? status + (size_t)b * ALILQR_STATUS_WORDS : NULL, NULL);
+    or_u_offset = NULL;
     if (r != 0) rc = r;
   }
   (void)threads;
   return rc;
+}
+
+int32_t oracle_solve_batch(const alilqr_problem* p,
+                           const double* x0, const double* goals,
+                           const double* Q, const double* R, const double* cons,
+                           double* x_out, double* u_out, double* node_x, double* node_u,
+                           double* x_init, double* u_init, double* cost, double* viol,
+                           double* lam, double* mu, int32_t* status, int32_t threads) {
+  return oracle_solve_batch_multistart(p, x0, goals, Q, R, cons, NULL, x_out, u_out, node_x, node_u, x_init, u_init,
+                                       cost, viol, lam, mu, status, threads);
 }
 
 int32_t oracle_linearize_batch(const alilqr_problem* p,

@@ -362,6 +362,7 @@ static void nw_initial_guess(nw_solver* s, const double* x0) {
     for (int j = 0; j < m; ++j) {
       double acc = 0.0;
       for (int i = 0; i < n; ++i) acc += (-K[j * n + i]) * (s->x[t * n + i] - nd->goal[i]);
+      if (or_u_offset) acc = acc + or_u_offset[t * m + j];
       s->u[t * m + j] = acc;
     }
     nw_dynamics(nd, s->x + t * n, s->u + t * m, s->x + (t + 1) * n);

@@ -32,6 +32,9 @@ void or_node_init(or_node* nd, const alilqr_problem* p, int t,
 void or_py_dynamics(const or_node* nd, const double* s, const double* u, double* next);
 void or_py_jacobian(const or_node* nd, const double* s, const double* u, double* A, double* B);
 
+/* multi-start: offsets [H][m] added to the initial-guess controls of the solve running on this thread, or NULL */
+extern _Thread_local const double* or_u_offset;
+
 /* NEW_AL generation (alilqr_oracle_new.c) */
 int32_t or_new_solve(const alilqr_problem* p,
                      const double* x0, const double* goals,

@@ -24,6 +24,7 @@ def lib():
         _LIB = C.CDLL(path)
         _LIB.oracle_solve.restype = C.c_int32
         _LIB.oracle_solve_batch.restype = C.c_int32
+        _LIB.oracle_solve_batch_multistart.restype = C.c_int32
         _LIB.oracle_linearize_batch.restype = C.c_int32
         _LIB.oracle_max_threads.restype = C.c_int32
     return _LIB
@@ -33,12 +34,14 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def solve_batch(desc, x0, goals, Q, R, cons, threads=0, extras=True):
+def solve_batch(desc, x0, goals, Q, R, cons, threads=0, extras=True, u_offset=None):
     """Run the oracle on a batch; arrays are host numpy float64, C-contiguous."""
     B, H, n, m, c = desc.batch, desc.horizon, desc.n, desc.m, desc.c
     out = capi.alloc_outputs_numpy(B, H, n, m, c, extras)
     args = [np.ascontiguousarray(a, dtype=np.float64) for a in (x0, goals, Q, R, cons)]
-    rc = lib().oracle_solve_batch(C.byref(desc), *[_p(a) for a in args],
+    uo = None if u_offset is None else np.ascontiguousarray(u_offset, dtype=np.float64)
+    assert uo is None or uo.size == B * H * m
+    rc = lib().oracle_solve_batch_multistart(C.byref(desc), *[_p(a) for a in args], _p(uo),
                                   _p(out["x"]), _p(out["u"]), _p(out.get("node_x")), _p(out.get("node_u")),
                                   _p(out.get("x_init")), _p(out.get("u_init")), _p(out["cost"]), _p(out.get("viol")),
                                   _p(out.get("lam")), _p(out.get("mu")), _p(out.get("status")), C.c_int32(threads))

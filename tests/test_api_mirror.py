@@ -118,3 +118,40 @@ def test_flat_module_names_of_the_reference_import(monkeypatch):
         m = importlib.import_module(mod)
         assert hasattr(m, name)
         sys.modules.pop(mod, None)
+
+
+def test_pybind_shaped_module_surface(monkeypatch):
+    """Names and constructor shapes of al_ilqr_cpp/ilqr_pybind.cc:37-79 for the linear / box families."""
+    import os
+    import sys
+    monkeypatch.syspath_prepend(os.path.join(os.path.dirname(capi.__file__), "compat"))
+    sys.modules.pop("ilqr_pybind", None)
+    import ilqr_pybind as ip
+    box = ip.BoxConstraints6_2([-1] * 6, [1] * 6, [-2, -3], [2, 3])
+    assert (box.get_state_dim(), box.get_control_dim(), box.get_constraint_dim()) == (6, 2, 16)
+    A, B = box.constraints_jacobian()
+    assert np.array_equal(A[:6], np.eye(6)) and np.array_equal(A[6:12], -np.eye(6)) and not A[12:].any()
+    assert np.array_equal(B[12:14], np.eye(2)) and np.array_equal(B[14:], -np.eye(2))
+    assert np.array_equal(box.Cv, [-1] * 6 + [-1] * 6 + [-2, -3, -2, -3])
+    assert getattr(box, "lambda").shape == (16,) and box.mu == 1.0
+    setattr(box, "lambda", np.arange(16.0))
+    box.update_mu(8.0)
+    node = ip.NewBicycleNodeBoxConstraints6_2(3.0, 0.1, 0.001, np.zeros(6), np.eye(6), np.eye(2), box)
+    # the constraint object is copied into the node (new_bicycle_node.h:169-170)
+    box.update_mu(1.0)
+    assert node.constraints_obj.mu == 8.0 and node.constraints_obj.lambda_[3] == 3.0
+    assert node.normalize_angle(0.5) == 0.5 and abs(node.normalize_angle(4.0) - (4.0 - 2 * np.pi)) < 1e-15
+    assert node.normalize_angle(-4.0) == float(np.fmod(-4.0 + np.pi, 2 * np.pi) - np.pi)   # C fmod: stays below -pi
+    with pytest.raises(TypeError):
+        ip.BoxConstraints6_2([-1] * 5, [1] * 6, [-2, -3], [2, 3])
+    with pytest.raises(TypeError):
+        ip.NewBicycleNodeBoxConstraints6_2(3.0, 0.1, 0.001, np.zeros(6), np.eye(6), np.eye(2), ip.BoxConstraints4_1([0] * 4, [1] * 4, [0], [1]))
+    lin = ip.LinearConstraints4_1_10(np.zeros((10, 4)), np.zeros((10, 1)), np.zeros(10))
+    lat = ip.NewLatBicycleNodeLinearConstraints4_1_10(3.0, 0.1, 0.001, 10.0, np.zeros(4), np.eye(4), np.eye(1), lin)
+    s = ip.NewALILQR4_1([lat] * 5, np.zeros(4))
+    assert s.get_x_list().shape == (4, 5) and s.get_u_list().shape == (1, 4)
+    desc, goals, Q, R, T = s._describe(7, 50, 100, 1e-3)
+    assert (desc.model, desc.mode, desc.horizon, desc.batch, desc.c, desc.table_nodes) == (capi.MODELS["lat_k"], 2, 4, 7, 10, 1)
+    assert desc.prm.viol_stop == 1e-3 and desc.prm.viol_lambda == 5e-3 and desc.prm.mu_gain == 100.0
+    with pytest.raises(TypeError):
+        ip.NewALILQR6_2([lat] * 5, np.zeros(6))

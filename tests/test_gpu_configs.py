@@ -1,0 +1,103 @@
+"""GPU parity on the remaining benchmark configurations (kinematic + static linear table, dynamic model at
+H = 100 in both Python generations, multi-start), each against the CPU oracle through the C ABI.
+
+Tolerance 1e-6 relative on x, u and the final cost, asserted on the solves the oracle itself reproduces from a start
+state moved by 1e-13 (the rest amplify one rounding error beyond any fixed tolerance; their fraction is bounded
+below per configuration).  NEW_AL cases are parity-unpinned against the C++ reference (see test_gpu_new_al.py).
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle_lib as ol
+from ilqr_amd import batch, capi, problems, sharding
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def to_np(out):
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def worst_err(o, ref, i):
+    ex = gu.rel_err(o["x"][i], ref["x"][i])
+    eu = gu.rel_err(o["u"][i], ref["u"][i])
+    ec = abs(o["cost"][i] - ref["cost"][i]) / max(1.0, abs(ref["cost"][i]))
+    w = max(ex, eu, ec)
+    return w if np.isfinite(w) else np.inf
+
+
+def stable_mask(prob, ref, u_offset=None, probes=2):
+    desc, x0 = prob[0], prob[1]
+    rng = np.random.default_rng(4)
+    scale = np.zeros(x0.shape[1]); scale[1:3] = 1e-13
+    ok = np.ones(desc.batch, dtype=bool)
+    for _ in range(probes):
+        ref2 = ol.solve_batch(desc, x0 + rng.uniform(-1, 1, size=x0.shape) * scale, *prob[2:6], u_offset=u_offset)
+        ok &= np.array([worst_err(ref2, ref, i) < 1e-8 for i in range(desc.batch)])
+    return ok
+
+
+CASES = {
+    # name: (generator, fraction of solves that must be pinned, compare iteration counts)
+    "kin_linear_new_al": (lambda: problems.kin_linear(48), 0.5, True),
+    "dyn_legacy_h100": (lambda: problems.full_legacy("dyn", 32, 100, 2), 0.5, True),
+    # FastILQR stops its inner loop on |dJ| < 1e-8, i.e. on rounding noise of a cost of 1e4: results are
+    # pinned, iteration counts are not
+    "fast_box_plus_linear_h50": (lambda: problems.fast_box_linear(32, H=50), 0.8, False),
+    # at H = 100 the same solver is ill-conditioned enough that the oracle reproduces few of its own solves to
+    # 1e-8; those few are held to 1e-6, the rest to agreement of the converged cost
+    "fast_box_plus_linear_h100": (lambda: problems.fast_box_linear(32), 0.0, False),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_configuration_matches_oracle(name):
+    gen, floor, counts = CASES[name]
+    prob = gen()
+    ref = ol.solve_batch(*prob)
+    o = to_np(batch.solve_batch(*prob))
+    ok = stable_mask(prob, ref)
+    assert ok.mean() >= floor, (name, ok.mean())
+    for i in np.nonzero(ok)[0]:
+        assert worst_err(o, ref, i) < TOL, (name, i, o["status"][i], ref["status"][i])
+    assert gu.rel_err(o["x_init"], ref["x_init"]) < 1e-12
+    if counts:
+        assert (o["status"][ok] == ref["status"][ok]).all(axis=1).mean() > 0.9
+    # every solve, pinned or not: same stopping state, and converged costs that agree to 1e-3
+    conv = ((o["status"][:, 2] & capi.FLAG_VIOL_OK) != 0) & ((ref["status"][:, 2] & capi.FLAG_VIOL_OK) != 0)
+    assert conv.mean() > 0.8
+    rel = np.abs(o["cost"][conv] - ref["cost"][conv]) / np.maximum(1.0, np.abs(ref["cost"][conv]))
+    assert np.mean(rel < 1e-3) > 0.8, np.sort(rel)[-5:]
+
+
+@pytest.mark.parametrize("mode", ["new_al", "legacy"])
+def test_multi_start_matches_oracle_and_picks_the_same_winner(mode):
+    scen, starts, H = 6, 16, 50
+    if mode == "new_al":
+        desc, x0, goals, Q, R, cons, uo = problems.multi_start(scen, starts, H=H)
+    else:
+        desc, _, goals, Q, R, cons = problems.lat_legacy(scen * starts, H=H)
+        _, x0, _, _, _, _, uo = problems.multi_start(scen, starts, H=H)
+    prob = (desc, x0, goals, Q, R, cons)
+    ref = ol.solve_batch(*prob, u_offset=uo)
+    o = to_np(batch.solve_batch(*prob, u_offset=uo))
+    assert gu.rel_err(o["u_init"], ref["u_init"]) < 1e-12
+    # start 0 of every scenario is the unperturbed problem
+    base = to_np(batch.solve_batch(*prob))
+    assert np.array_equal(o["x"][::starts], base["x"][::starts])
+    assert np.abs(o["u_init"][1] - o["u_init"][0]).max() > 1e-3
+    ok = stable_mask(prob, ref, u_offset=uo)
+    assert ok.mean() >= (0.8 if mode == "new_al" else 0.3), ok.mean()
+    for i in np.nonzero(ok)[0]:
+        assert worst_err(o, ref, i) < TOL, (mode, i)
+    # arg-min over the starts of a scenario: same best cost where every start of the scenario is pinned
+    bc, bi = sharding.best_start(o["cost"], starts)
+    rc, ri = sharding.best_start(ref["cost"], starts)
+    for s in range(scen):
+        if ok[s * starts:(s + 1) * starts].all():
+            assert abs(bc[s] - rc[s]) <= TOL * max(1.0, abs(rc[s]))
+            second = np.partition(ref["cost"][s * starts:(s + 1) * starts], 1)[1]
+            if second - rc[s] > 1e-5 * max(1.0, abs(rc[s])):
+                assert bi[s] == ri[s]

@@ -72,3 +72,33 @@ def test_solve_batch_extension_runs_many_start_states():
     out = ILQR(nodes).solve_batch(g["x0"][idx])
     assert gu.rel_err(out["x"].cpu().numpy(), g["x"][idx]) < TOL
     assert gu.rel_err(out["cost"].cpu().numpy(), g["cost"][idx]) < TOL
+
+
+def test_pybind_shaped_solver_runs_the_reference_script_flow():
+    """The flow of cilqr/test_pybind.py:141-215 (box constraints, H=30, optimize(50, 100, 1e-4)) through the
+    ilqr_pybind-shaped classes, checked against the CPU oracle on the same problem."""
+    import oracle_lib as ol
+    from ilqr_amd import problems, pybind_api as ip
+    v, dt, L, k, H = 10.0, 0.1, 3.0, 0.001, 30
+    goals = problems.s_curve_goals(v, dt, H, True)
+    Q = np.diag([1e-1, 1e-1, 1e-0, 1e-9, 1e-6, 1e-6]) * 1e3
+    R = np.diag([1.0, 1.0]) * 1e2
+    cons = ip.BoxConstraints6_2([-1000, -1000, -2 * np.pi, -10, -100, -10], [1000, 1000, 2 * np.pi, 10, 100, 10],
+                                [-0.2, -1], [0.2, 1])
+    nodes = [ip.NewBicycleNodeBoxConstraints6_2(L, dt, k, goals[i], Q, R, cons) for i in range(H + 1)]
+    x0 = np.array([0, 0, 0, 0, v, 0.0])
+    s = ip.NewALILQR6_2(nodes, x0)
+    s.optimize(50, 100, 1e-4)
+    x, u = s.get_x_list(), s.get_u_list()
+    assert x.shape == (6, H + 1) and u.shape == (2, H)
+    desc, g, Qt, Rt, T = s._describe(1, 50, 100, 1e-4)
+    ref = ol.solve_batch(desc, x0[None], g, Qt, Rt, T)
+    assert gu.rel_err(x.T, ref["x"][0]) < 1e-6 and gu.rel_err(u.T, ref["u"][0]) < 1e-6
+    assert s.last_status["inner"] == ref["status"][0, 0] and s.last_status["violation"] < 1e-4
+    assert np.array_equal(nodes[3].constraints_obj.lambda_, ref["lam"][0, 3]) or \
+        gu.rel_err(nodes[3].constraints_obj.lambda_, ref["lam"][0, 3]) < 1e-6
+    # per-node methods go through the node-evaluation kernel
+    f = nodes[0].dynamics(x[:, 0], u[:, 0])
+    assert gu.rel_err(f, x[:, 1]) < 1e-14
+    fx, fu = nodes[0].dynamics_jacobian(x[:, 0], u[:, 0])
+    assert fx.shape == (6, 6) and fu.shape == (6, 2)
