@@ -86,18 +86,22 @@ int32_t check_problem(const alilqr_problem* p, Dims* d) {
   return ALILQR_OK;
 }
 
-// lanes per problem: enough lanes to put every line-search trial of the
-// reference in flight, unless the batch alone already fills the machine
+// Lanes per problem.  Wide groups put every line-search trial of a round in flight and shorten the solve of
+// one problem; narrow groups put more problems into a wave and raise throughput once the batch alone fills
+// the machine.  Measured on MI355X (batch 4096 and 65536, every generation): the wide width wins while the
+// batch fits in 2 waves per SIMD at that width, the next narrower one beyond; a single lane per problem never
+// wins (its roll-outs are sequential and the kernel spills).
 int pick_group(const alilqr_problem* p) {
   if (const char* e = std::getenv("ALILQR_LANES")) {
     int g = std::atoi(e);
     if (g == 1 || g == 4 || g == 8 || g == 16 || g == 32) return g;
   }
   const long target_waves = 2048;   // 2 waves on each of the 1024 SIMDs
-  for (int g : {32, 8}) {
-    if ((long)p->batch * g / 64 <= target_waves) return g;
-  }
-  return 1;
+  // LEGACY needs up to 27 trials per round; the other generations accept early (FAST) or stop at 10 (NEW_AL),
+  // and their 6-state kernels carry twice the registers per lane
+  const bool wide = (p->mode == ALILQR_MODE_LEGACY) || (p->n == 4);
+  const int g0 = wide ? 32 : 16, g1 = wide ? 16 : 8;
+  return ((long)p->batch * g0 / 64 <= target_waves) ? g0 : g1;
 }
 
 struct Plan {

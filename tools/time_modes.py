@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Development aid: kernel time of one batch solve per solver generation / model (inputs resident, HIP events)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from ilqr_amd import batch, problems
+
+def main():
+    B = int(os.environ.get("B", "4096"))
+    sets = {
+        "legacy lat H50": problems.lat_legacy(B),
+        "legacy dyn H100": problems.full_legacy("dyn", B, 100, 2),
+        "fast box H50": problems.fast_box(B),
+        "fast box+linear H100": problems.fast_box_linear(B),
+        "new_al box6 H50": problems.new_al_box(B),
+        "new_al lat4 H50": problems.new_al_lat(B),
+        "new_al kin+linear H50": problems.kin_linear(B),
+    }
+    only = sys.argv[1:]
+    for name, prob in sets.items():
+        if only and not any(o in name for o in only):
+            continue
+        s = batch.BatchSolver(*prob)
+        s.run(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            o = s.run()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        st = o["status"].cpu().numpy()
+        print(f"{name:24s} lanes={os.environ.get('ALILQR_LANES','auto'):>4s} B={B} {ms:8.2f} ms {B / ms * 1e3:10.0f} solves/s  "
+              f"inner mean {st[:,0].mean():6.1f} max {st[:,0].max():4d}  rollouts mean {st[:,3].mean():7.1f}  converged {np.mean((st[:,2] & 1) != 0):.3f}", flush=True)
+
+if __name__ == "__main__":
+    main()
