@@ -24,8 +24,9 @@
 //        G > 1: the block is contiguous (problem-major), so a sequential sweep reads one
 //        short run of doubles per step from one base address; G = 1: element-major /
 //        group-minor, so the 64 problems of a wave read one contiguous run per element.
-//   trj  [2][T][NG*SS] candidate trajectories: SS slots per problem and parity, kept only for
-//        the trials that usually win; any other winner is rolled out a second time.
+//   trj  candidate trajectories, SS slots per problem and parity, kept only for the trials that usually
+//        win (any other winner is rolled out a second time).  G > 1: [group][2][SS][T], contiguous per
+//        roll-out; G = 1: [2][T][NG*SS], lane-minor.
 //   ucum [H*M][NG*G]   LEGACY: accumulated controls of the open-loop trials, lane-minor.
 // The current trajectory of a problem is the pair (slot, parity) of the last
 // accepted roll-out; nothing is copied on acceptance.  Sequential sweeps (P2, P3)
@@ -798,8 +799,11 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   int outer = 0, inner = 0, n_inner = 0, n_trials = 0;
   bool outer_start = false;
 
-  // candidate trajectories: [parity][element][group * SS + slot]
+  // candidate trajectories.  G > 1: [group][parity][slot][element], a lane writes its roll-out as one contiguous
+  // run and a node's (x, u) is one short run; G = 1: [parity][element][group * SS + slot], lane-minor, so the
+  // 64 problems of a wave store one contiguous run per element.
   auto trj_at = [&](int par, int off, int slot) -> double* {
+    if (PM) return trj + ((gid * 2 + par) * SS + slot) * (size_t)T + off;
     return trj + ((size_t)par * T + off) * (NG * SS) + gid * SS + slot;
   };
   // accumulated controls of the LEGACY open-loop trials: [t * M + r][global lane]
