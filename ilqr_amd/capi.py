@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 STATUS_WORDS = 4
 
 MODELS = {"lat": 0, "kin": 1, "dyn": 2, "dyn_mid": 3, "lat_k": 4, "new_bicycle": 5}
@@ -36,6 +36,7 @@ class Problem(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("model", C.c_int32), ("mode", C.c_int32),
                 ("horizon", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("c", C.c_int32),
                 ("batch", C.c_int32), ("goal_batch", C.c_int32), ("table_nodes", C.c_int32),
+                ("cons_kind", C.c_int32), ("reserved", C.c_int32),
                 ("L", C.c_double), ("dt", C.c_double), ("v", C.c_double), ("k", C.c_double),
                 ("prm", Params)]
 
@@ -53,8 +54,11 @@ def default_params(mode):
     raise ValueError(f"unknown solver mode {mode}")
 
 
+CONS_LINEAR, CONS_QUADRATIC = 0, 1
+
+
 def make_problem(model, mode, horizon, batch, L, dt, v=0.0, k=0.0, c=None,
-                 goal_batch=1, table_nodes=1, params=None):
+                 goal_batch=1, table_nodes=1, params=None, cons_kind=CONS_LINEAR):
     model_id = MODELS[model] if isinstance(model, str) else int(model)
     mode_id = MODES[mode] if isinstance(mode, str) else int(mode)
     n, m = MODEL_DIMS[model_id]
@@ -64,7 +68,7 @@ def make_problem(model, mode, horizon, batch, L, dt, v=0.0, k=0.0, c=None,
         c = 2 * (n + m)
     prm = params if params is not None else default_params(mode_id)
     return Problem(ABI_VERSION, model_id, mode_id, int(horizon), n, m, int(c), int(batch),
-                   int(goal_batch), int(table_nodes), float(L), float(dt), float(v), float(k), prm)
+                   int(goal_batch), int(table_nodes), int(cons_kind), 0, float(L), float(dt), float(v), float(k), prm)
 
 
 def pack_box(state_min, state_max, control_min, control_max):
@@ -78,10 +82,18 @@ def pack_linear(A, B, Cv):
     return np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in (A, B, Cv)])
 
 
+def pack_quadratic(Qc, A, B, Cv):
+    """NEW_AL quadratic table of one node: A (c x n) | B (c x m) | C (c) | Qc (c x n x n)."""
+    return np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in (A, B, Cv, Qc)])
+
+
 def cons_words(desc):
     if desc.mode == MODES["legacy"]:
         return 2 * desc.n + 2 * desc.m
-    return desc.c * (desc.n + desc.m + 1)
+    w = desc.c * (desc.n + desc.m + 1)
+    if desc.cons_kind == CONS_QUADRATIC:
+        w += desc.c * desc.n * desc.n
+    return w
 
 
 def alloc_outputs_numpy(B, H, n, m, c, extras=True):

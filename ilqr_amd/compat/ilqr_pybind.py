@@ -5,4 +5,5 @@ from ilqr_amd.pybind_api import (BoxConstraints4_1, BoxConstraints6_2, LinearCon
                                  LinearConstraints4_1_10, LinearConstraints6_2_16, NewALILQR4_1, NewALILQR6_2,
                                  NewBicycleNodeBoxConstraints6_2, NewBicycleNodeLinearConstraints6_2_16,
                                  NewLatBicycleNodeBoxConstraints4_1, NewLatBicycleNodeLinearConstraints4_1_6,
-                                 NewLatBicycleNodeLinearConstraints4_1_10)
+                                 NewLatBicycleNodeLinearConstraints4_1_10, QuadraticConstraints4_1_3, QuadraticConstraints6_2_5,
+                                 NewBicycleNodeQuadraticConstraints6_2_5, NewLatBicycleNodeQuadraticConstraints4_1_3)

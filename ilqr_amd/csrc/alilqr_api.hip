@@ -64,6 +64,10 @@ int32_t check_problem(const alilqr_problem* p, Dims* d) {
   if (p->horizon < 1 || p->batch < 0) { set_err("horizon must be >= 1 and batch >= 0"); return ALILQR_E_ARG; }
   if (p->goal_batch != 1 && p->goal_batch != p->batch) { set_err("goal_batch must be 1 or batch"); return ALILQR_E_ARG; }
   if (p->table_nodes != 1 && p->table_nodes != p->horizon + 1) { set_err("table_nodes must be 1 or horizon+1"); return ALILQR_E_ARG; }
+  if (p->cons_kind != ALILQR_CONS_LINEAR && p->cons_kind != ALILQR_CONS_QUADRATIC) { set_err("unknown cons_kind"); return ALILQR_E_ARG; }
+  if (p->cons_kind == ALILQR_CONS_QUADRATIC && p->mode != ALILQR_MODE_NEW_AL) {
+    set_err("quadratic constraint tables are defined for NEW_AL"); return ALILQR_E_ARG;
+  }
   if (p->mode == ALILQR_MODE_LEGACY) {
     if (p->c != 2 * (p->n + p->m)) { set_err("LEGACY needs c = 2(n+m)"); return ALILQR_E_ARG; }
     if (p->model != ALILQR_MODEL_LAT && p->model != ALILQR_MODEL_KIN && p->model != ALILQR_MODEL_DYN) {
@@ -165,7 +169,7 @@ int32_t launch_g(const alilqr::KArgs& ka, int G, int waves, hipStream_t st) {
 // node evaluation kernel (alilqr_linearize_batch): one thread per node
 // ---------------------------------------------------------------------------
 struct LArgs {
-  int B, H, C, goal_batch, table_nodes;
+  int B, H, C, goal_batch, table_nodes, quad;
   alilqr::ModelConst mc;
   const double *x, *u, *lam, *mu, *goals, *Q, *R, *cons;
   double *f, *fx, *fu, *l, *lx, *lu, *lxx, *luu;
@@ -183,10 +187,12 @@ __global__ __launch_bounds__(256) void linearize_kernel(LArgs a) {
   if (i >= total) return;
   const int b = (int)(i / (a.H + 1)), t = (int)(i % (a.H + 1));
   const int tt = (a.table_nodes > 1) ? t : 0;
-  const int cw = (MODE == ALILQR_MODE_LEGACY) ? (2 * N + 2 * M) : a.C * (N + M + 1);
+  const int cw = (MODE == ALILQR_MODE_LEGACY) ? (2 * N + 2 * M) : a.C * (N + M + 1) + (a.quad ? a.C * N * N : 0);
   KArgs ka{};
   ka.C = a.C;
   ka.qdiag = 0;
+  ka.quad = a.quad;
+  ka.quad_rows = ~0ull;   // no row is skipped here: an all-zero matrix contributes exact zeros
   double x[N], u[M], xn[N], ac[MD::NA], bc[MD::NB], S[N][N], Bm[N][M];
 #pragma unroll
   for (int q = 0; q < N; ++q) x[q] = a.x[i * N + q];
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(LArgs a) {
   MD::step(a.mc, x, u, xn);
   MD::jac(a.mc, x, u, ac, bc);
   expand_jac<MD>(a.mc, ac, bc, S, Bm);
-  if (MODE != ALILQR_MODE_NEW_AL) {
+  if (!is_new_al(MODE)) {
     // the Python node keeps its state angle-wrapped from its first cost call on
     x[2] = wrap_py(x[2]);
     x[3] = wrap_py(x[3]);
@@ -325,6 +331,7 @@ int32_t alilqr_solve_batch_multistart(const alilqr_problem* p,
   ka.B = p->batch; ka.NG = pl.NG; ka.H = p->horizon; ka.C = p->c;
   ka.goal_batch = p->goal_batch; ka.table_nodes = p->table_nodes;
   ka.mc = {p->L, p->dt, p->v, p->k};
+  ka.quad = (p->cons_kind == ALILQR_CONS_QUADRATIC) ? 1 : 0;
   ka.prm = p->prm;
   ka.x0 = x0; ka.goals = goals; ka.Q = Q; ka.R = R; ka.cons = cons; ka.u_off = u_offset;
   ka.x_out = x_out; ka.u_out = u_out; ka.node_x = node_x; ka.node_u = node_u;
@@ -345,8 +352,13 @@ int32_t alilqr_solve_batch_multistart(const alilqr_problem* p,
   } else if (p->mode == ALILQR_MODE_FAST) {
     if (p->model == ALILQR_MODEL_DYN_MID) return launch_g<ALILQR_MODEL_DYN_MID, ALILQR_MODE_FAST>(ka, pl.G, waves, st);
   } else if (p->mode == ALILQR_MODE_NEW_AL) {
-    if (p->model == ALILQR_MODEL_LAT_K) return launch_g<ALILQR_MODEL_LAT_K, ALILQR_MODE_NEW_AL>(ka, pl.G, waves, st);
-    if (p->model == ALILQR_MODEL_NEW_BICYCLE) return launch_g<ALILQR_MODEL_NEW_BICYCLE, ALILQR_MODE_NEW_AL>(ka, pl.G, waves, st);
+    const bool quad = (p->cons_kind == ALILQR_CONS_QUADRATIC);
+    if (p->model == ALILQR_MODEL_LAT_K)
+      return quad ? launch_g<ALILQR_MODEL_LAT_K, alilqr::kModeNewAlQuad>(ka, pl.G, waves, st)
+                  : launch_g<ALILQR_MODEL_LAT_K, ALILQR_MODE_NEW_AL>(ka, pl.G, waves, st);
+    if (p->model == ALILQR_MODEL_NEW_BICYCLE)
+      return quad ? launch_g<ALILQR_MODEL_NEW_BICYCLE, alilqr::kModeNewAlQuad>(ka, pl.G, waves, st)
+                  : launch_g<ALILQR_MODEL_NEW_BICYCLE, ALILQR_MODE_NEW_AL>(ka, pl.G, waves, st);
   }
   set_err("unsupported model / mode combination");
   return ALILQR_E_ARG;
@@ -370,6 +382,7 @@ int32_t alilqr_linearize_batch(const alilqr_problem* p,
   }
   LArgs a{};
   a.B = p->batch; a.H = p->horizon; a.C = p->c; a.goal_batch = p->goal_batch; a.table_nodes = p->table_nodes;
+  a.quad = (p->cons_kind == ALILQR_CONS_QUADRATIC) ? 1 : 0;
   a.mc = {p->L, p->dt, p->v, p->k};
   a.x = x; a.u = u; a.lam = lam; a.mu = mu; a.goals = goals; a.Q = Q; a.R = R; a.cons = cons;
   a.f = f; a.fx = fx; a.fu = fu; a.l = l; a.lx = lx; a.lu = lu; a.lxx = lxx; a.luu = luu;
@@ -384,8 +397,13 @@ int32_t alilqr_linearize_batch(const alilqr_problem* p,
       default: set_err("unsupported model / mode combination"); return ALILQR_E_ARG;
     }
   } else if (p->mode == ALILQR_MODE_NEW_AL) {
-    if (p->model == ALILQR_MODEL_LAT_K) hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_LAT_K, ALILQR_MODE_NEW_AL>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_NEW_BICYCLE, ALILQR_MODE_NEW_AL>), grid, block, 0, st, a);
+    if (a.quad) {
+      if (p->model == ALILQR_MODEL_LAT_K) hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_LAT_K, alilqr::kModeNewAlQuad>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_NEW_BICYCLE, alilqr::kModeNewAlQuad>), grid, block, 0, st, a);
+    } else {
+      if (p->model == ALILQR_MODEL_LAT_K) hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_LAT_K, ALILQR_MODE_NEW_AL>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_NEW_BICYCLE, ALILQR_MODE_NEW_AL>), grid, block, 0, st, a);
+    }
   } else {
     hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_DYN_MID, ALILQR_MODE_FAST>), grid, block, 0, st, a);
   }

@@ -63,6 +63,8 @@ __device__ __forceinline__ ctab as_ctab(const double* p) {
 struct KArgs {
   int B, NG, H, C, goal_batch, table_nodes;
   int qdiag;                  // every Q table is diagonal (set in the kernel prologue)
+  int quad;                   // constraint tables carry per-row quadratic terms (NEW_AL, ALILQR_CONS_QUADRATIC)
+  unsigned long long quad_rows;   // rows whose quadratic matrix is not all zero, over all tables (kernel prologue)
   ModelConst mc;
   alilqr_params prm;
   const double *x0, *goals, *Q, *R, *cons;
@@ -567,11 +569,31 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
 // NEW_AL: the C++ generation (al_ilqr_cpp/constraints/constraints.h:514-1040, model/new_bicycle_node.h:702-910).
 // Same projection-form AL as FAST with three differences: only diag(Q), diag(R) enter the cost, the active-row
 // mask is "projected multiplier < 0" (a row sitting exactly at zero drops out), and the state is not wrapped.
-template <int MODEL>
-struct NodeOps<MODEL, ALILQR_MODE_NEW_AL> {
+// Kernel-internal mode value: NEW_AL with quadratic constraint tables.  A separate instantiation keeps the
+// quadratic-row code (and its registers) out of the kernels that solve linear tables.
+constexpr int kModeNewAlQuad = 3;
+__host__ __device__ constexpr bool is_new_al(int mode) { return mode == ALILQR_MODE_NEW_AL || mode == kModeNewAlQuad; }
+
+template <int MODEL, bool QUAD>
+struct NewAlOps {
   using MD = Model<MODEL>;
   static constexpr int N = MD::N, M = MD::M;
 
+  // x' Qc_i x as (x' Qc_i) x  (quadratic_constraints.h:21-24); rows with an all-zero matrix are skipped (exact zero)
+  __device__ static __forceinline__ double quad_term(const KArgs& a, ctab tab, const double* x, int i) {
+    if (!QUAD || !((a.quad_rows >> i) & 1ull)) return 0.0;
+    ctab Qi = tab + a.C * (N + M + 1) + (size_t)i * N * N;
+    double q = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) t += x[k] * Qi[k * N + j];
+      q += t * x[j];
+    }
+    return q;
+  }
+  // A x + B u + C (linear_constraints.h:176-181); quadratic tables put x'Qx first in the sum (quadratic_constraints.h:26)
   __device__ static __forceinline__ double cval(const KArgs& a, ctab tab, const double* x, const double* u, int i) {
     ctab A = tab, Bm = tab + a.C * N, Cv = tab + a.C * (N + M);
     double ax = 0.0, bu = 0.0;
@@ -579,7 +601,20 @@ struct NodeOps<MODEL, ALILQR_MODE_NEW_AL> {
     for (int j = 0; j < N; ++j) ax += A[i * N + j] * x[j];
 #pragma unroll
     for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
+    if (QUAD) return ((quad_term(a, tab, x, i) + ax) + bu) + Cv[i];
     return ax + bu + Cv[i];
+  }
+  // one column of parallel_constraints: the quadratic term comes last (quadratic_constraints.h:44)
+  __device__ static __forceinline__ double par_cval(const KArgs& a, ctab tab, const double* x, const double* u, int i) {
+    ctab A = tab, Bm = tab + a.C * N, Cv = tab + a.C * (N + M);
+    double ax = 0.0, bu = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) ax += A[i * N + j] * x[j];
+#pragma unroll
+    for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
+    double c = ax + bu + Cv[i];
+    if (QUAD) c = c + quad_term(a, tab, x, i);
+    return c;
   }
   __device__ static double cost(const KArgs& a, ctab Q, ctab R, ctab tab,
                                 const double* x, const double* u, const double* g,
@@ -609,7 +644,7 @@ struct NodeOps<MODEL, ALILQR_MODE_NEW_AL> {
     for (int j = 0; j < M; ++j) cr += (R[j * M + j] * u[j]) * u[j];
     for (int i = 0; i < a.C; ++i) {
       double l = lam[i * ls];
-      double pr = fmin(l - mu * cval(a, tab, x, u, i), 0.0);
+      double pr = fmin(l - mu * par_cval(a, tab, x, u, i), 0.0);
       al += pr * pr - l * l;
     }
     al = 0.5 / mu * al;
@@ -621,7 +656,7 @@ struct NodeOps<MODEL, ALILQR_MODE_NEW_AL> {
                                     double* rec, size_t rs) {
     using LL = LinLayout<MD>;
     ctab A = tab, Bm = tab + a.C * N;
-    double e[N], jx[N], ju[M], hx[N][N], hu[M][M];
+    double e[N], jx[N], ju[M], hx[N][N], hu[M][M], tq[N][N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { e[i] = x[i] - g[i]; jx[i] = 0.0; }
 #pragma unroll
@@ -629,7 +664,7 @@ struct NodeOps<MODEL, ALILQR_MODE_NEW_AL> {
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
-      for (int j = 0; j < N; ++j) hx[i][j] = 0.0;
+      for (int j = 0; j < N; ++j) { hx[i][j] = 0.0; tq[i][j] = 0.0; }
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
@@ -637,15 +672,32 @@ struct NodeOps<MODEL, ALILQR_MODE_NEW_AL> {
     for (int i = 0; i < a.C; ++i) {
       double lp = fmin(lam[i * ls] - mu * cval(a, tab, x, u, i), 0.0);
       double on = (lp >= 0.0) ? 0.0 : 1.0;
-      double pa[N], pb[M];
+      double cx[N], pa[N], pb[M];
 #pragma unroll
-      for (int j = 0; j < N; ++j) { pa[j] = on * A[i * N + j]; jx[j] += pa[j] * lp; }
+      for (int j = 0; j < N; ++j) cx[j] = A[i * N + j];
+      if (QUAD && ((a.quad_rows >> i) & 1ull)) {
+        // c_x row: A_i + 2 Qc_i x ; constraint Hessian 2 Qc_i weighted by the projected multiplier
+        // (quadratic_constraints.h:47-55, 86-88; constraints.h:797-802, 1341-1345)
+        ctab Qi = tab + a.C * (N + M + 1) + (size_t)i * N * N;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          double qx = 0.0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            qx += (2 * Qi[j * N + k]) * x[k];
+            tq[j][k] += (2.0 * Qi[j * N + k]) * lp;
+          }
+          cx[j] = cx[j] + qx;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < N; ++j) { pa[j] = on * cx[j]; jx[j] += pa[j] * lp; }
 #pragma unroll
       for (int j = 0; j < M; ++j) { pb[j] = on * Bm[i * M + j]; ju[j] += pb[j] * lp; }
 #pragma unroll
       for (int p = 0; p < N; ++p)
 #pragma unroll
-        for (int q = 0; q < N; ++q) hx[p][q] += (mu * pa[p]) * A[i * N + q];
+        for (int q = 0; q < N; ++q) hx[p][q] += (mu * pa[p]) * cx[q];
 #pragma unroll
       for (int p = 0; p < M; ++p)
 #pragma unroll
@@ -658,7 +710,7 @@ struct NodeOps<MODEL, ALILQR_MODE_NEW_AL> {
       for (int j = 0; j < N; ++j) s += (2 * Q[i * N + j]) * e[j];
       rec[(LL::oLx + i) * rs] = s + (-jx[i]);
 #pragma unroll
-      for (int j = 0; j < N; ++j) rec[(LL::oLxx + i * N + j) * rs] = 2 * Q[i * N + j] + hx[i][j];
+      for (int j = 0; j < N; ++j) rec[(LL::oLxx + i * N + j) * rs] = 2 * Q[i * N + j] + (hx[i][j] - 1.0 * tq[i][j]);
     }
 #pragma unroll
     for (int i = 0; i < M; ++i) {
@@ -691,6 +743,11 @@ struct NodeOps<MODEL, ALILQR_MODE_NEW_AL> {
     }
   }
 };
+template <int MODEL>
+struct NodeOps<MODEL, ALILQR_MODE_NEW_AL> : NewAlOps<MODEL, false> {};
+template <int MODEL>
+struct NodeOps<MODEL, kModeNewAlQuad> : NewAlOps<MODEL, true> {};
+
 
 // ---------------------------------------------------------------------------
 // the kernel
@@ -709,7 +766,7 @@ template <class MD, int MODE>
 struct NodeRec {
   static constexpr int N = MD::N, M = MD::M;
   static constexpr bool LEGACY = (MODE == ALILQR_MODE_LEGACY);
-  static constexpr bool NEWAL = (MODE == ALILQR_MODE_NEW_AL);
+  static constexpr bool NEWAL = is_new_al(MODE);
   static constexpr int HX = LEGACY ? N : N * N, HU = LEGACY ? M : M * M, NF = NEWAL ? 7 : 0;
   static constexpr int oA = 0, oB = oA + MD::NA, oLx = oB + MD::NB, oLu = oLx + N, oHx = oLu + M, oHu = oHx + HX,
                        oF = oHu + HU, E = (oF + NF + 1) & ~1;
@@ -752,7 +809,8 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   using NR = NodeRec<MD, MODE>;
   constexpr int N = MD::N, M = MD::M;
   constexpr bool LEGACY = (MODE == ALILQR_MODE_LEGACY);
-  constexpr bool NEWAL = (MODE == ALILQR_MODE_NEW_AL);
+  constexpr bool NEWAL = is_new_al(MODE);
+  constexpr bool QUAD = (MODE == kModeNewAlQuad);
   constexpr bool PM = (G > 1);                         // block layout: problem-major (contiguous) or element-major
   constexpr int CL = LEGACY ? 2 * (N + M) : 1;         // multipliers held in registers (LEGACY only)
   constexpr int SS = TrjSlots<MODE>::SS;               // trajectory slots kept per problem and parity
@@ -773,7 +831,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   double* const linb = blk + (size_t)(H + 1) * RS * ES;
 
   double* const trj = a.trj;
-  const int cw = LEGACY ? (2 * N + 2 * M) : C * (N + M + 1);   // doubles per constraint table
+  const int cw = LEGACY ? (2 * N + 2 * M) : C * (N + M + 1) + (QUAD ? C * N * N : 0);   // doubles per constraint table
 
   // is every state-weight table diagonal?  (uniform scalar reads, once per kernel)
   {
@@ -784,6 +842,17 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         for (int j = 0; j < N; ++j)
           if (i != j && Qt[(size_t)t * N * N + i * N + j] != 0.0) diag = false;
     a.qdiag = diag ? 1 : 0;
+    // which constraint rows carry a quadratic term in any table
+    a.quad_rows = 0ull;
+    if (QUAD) {
+      ctab ct = as_ctab(a.cons);
+      for (int t = 0; t < a.table_nodes; ++t)
+        for (int i = 0; i < C; ++i) {
+          bool nz = false;
+          for (int e = 0; e < N * N; ++e) nz |= (ct[(size_t)t * cw + C * (N + M + 1) + i * N * N + e] != 0.0);
+          if (nz) a.quad_rows |= 1ull << i;
+        }
+    }
   }
 
   // number of line-search trials the reference can make: alpha = 1, 1/2, ... while alpha > alpha_min

@@ -174,3 +174,51 @@ def fast_box_linear(B, H=100, seed=2):
     Q = np.diag([1e-1, 1e-1, 1.0, 1e-9, 1e-6, 1e-6]) * 1e3
     R = np.eye(2) * 1e2
     return desc, full_start_states(B, seed), s_curve_goals(10.0, 0.1, H, True), Q, R, capi.pack_linear(A, Bm, C)
+
+
+def circle_rows(cx, cy, r, n):
+    """Circle obstacle (x-cx)^2 + (y-cy)^2 >= r^2 as one quadratic row x'Qx + Ax + C <= 0
+    (al_ilqr_cpp/test_new_al_ilqr.cc:83-104)."""
+    Qc = np.zeros((n, n)); Qc[0, 0] = Qc[1, 1] = -1.0
+    A = np.zeros(n); A[0], A[1] = 2 * cx, 2 * cy
+    return Qc, A, r * r - cx * cx - cy * cy
+
+
+def new_al_circle(B, H=50, seed=8, circle=(20.0, 12.0, 4.0), x0=None):
+    """NewALILQR<6,2> + NewBicycleNode + QuadraticConstraints<6,2,5>: one circle obstacle and the four
+    control-bound rows (al_ilqr_cpp/test_new_al_ilqr.cc:208-266; optimize(30, 100, 1e-3))."""
+    c, n, m = 5, 6, 2
+    Qc = np.zeros((c, n, n)); A = np.zeros((c, n)); Bm = np.zeros((c, m)); C = np.zeros(c)
+    Qc[0], A[0], C[0] = circle_rows(*circle, n)
+    Bm[1:] = [[1, 0], [0, 1], [-1, 0], [0, -1]]
+    C[1:] = [-0.2, -1.0, -0.2, -1.0]
+    desc = capi.make_problem("new_bicycle", "new_al", H, B, L=3.0, dt=0.1, v=10.0, k=0.001, c=c,
+                             cons_kind=capi.CONS_QUADRATIC)
+    desc.prm.max_outer, desc.prm.max_inner = 30, 100
+    desc.prm.viol_stop, desc.prm.viol_lambda = 1e-3, 5e-3
+    Q = np.diag([1e-1, 1e-1, 1.0, 1e-9, 1e-6, 1e-6]) * 1e3
+    R = np.eye(2) * 1e2
+    if x0 is None:
+        x0 = full_start_states(B, seed)
+    return desc, np.ascontiguousarray(x0, dtype=np.float64), s_curve_goals(10.0, 0.1, H, True), Q, R, \
+        capi.pack_quadratic(Qc, A, Bm, C)
+
+
+def new_al_lat_circle(B, H=30, seed=10, circle=(30.0, 11.0, 6.0), x0=None):
+    """NewALILQR<4,1> + NewLatBicycleNode + QuadraticConstraints<4,1,3>: circle + steering-rate bounds of 0.4
+    (cilqr/test_lat_bicycle_pybind.py:60-104; optimize(50, 100, 1e-4))."""
+    c, n, m = 3, 4, 1
+    Qc = np.zeros((c, n, n)); A = np.zeros((c, n)); Bm = np.zeros((c, m)); C = np.zeros(c)
+    Qc[0], A[0], C[0] = circle_rows(*circle, n)
+    Bm[1, 0], Bm[2, 0] = 1.0, -1.0
+    C[1] = C[2] = -0.4
+    desc = capi.make_problem("lat_k", "new_al", H, B, L=3.0, dt=0.1, v=10.0, k=0.001, c=c, cons_kind=capi.CONS_QUADRATIC)
+    desc.prm.max_outer, desc.prm.max_inner = 50, 100
+    desc.prm.viol_stop, desc.prm.viol_lambda = 1e-4, 5e-4
+    Q = np.diag([1e-1, 1e-1, 1.0, 1e-9]) * 1e6
+    R = np.eye(1) * 1e2
+    if x0 is None:
+        x0 = lat_start_states(B, seed)
+        x0[:, 2] += 1.0      # the script starts with a heading of 1 rad
+    return desc, np.ascontiguousarray(x0, dtype=np.float64), s_curve_goals(10.0, 0.1, H, False), Q, R, \
+        capi.pack_quadratic(Qc, A, Bm, C)

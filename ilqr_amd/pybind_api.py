@@ -91,6 +91,8 @@ class _Constraints:
     def get_current_constraints_index(self):
         return self._index
 
+    KIND = capi.CONS_LINEAR
+
     def table(self):
         """A | B | C packed the way the C ABI takes a linear table."""
         return capi.pack_linear(self.A, self.B, self.Cv)
@@ -125,6 +127,35 @@ class _BoxConstraints(_LinearConstraints):
         super().__init__(A, B, C)
 
 
+class _QuadraticConstraints(_Constraints):
+    """QuadraticConstraints<n, m, c>(Q, A, B, C, is_equality=False): c_i = x'Q_i x + A_i x + B_i u + C_i
+    (quadratic_constraints.h:6-98)."""
+    KIND = capi.CONS_QUADRATIC
+
+    def __init__(self, Q, A, B, C, is_equality=False):
+        super().__init__()
+        if is_equality:
+            raise NotImplementedError("equality constraints are not on the GPU path")
+        Q = list(Q)
+        if len(Q) != self.C:
+            raise TypeError(f"Q: expected {self.C} matrices, got {len(Q)}")
+        self.Qc = np.stack([_mat(q, self.N, self.N, "Q[i]") for q in Q])
+        self.A = _mat(A, self.C, self.N, "A")
+        self.B = _mat(B, self.C, self.M, "B")
+        self.Cv = _vec(C, self.C, "C")
+
+    def table(self):
+        return capi.pack_quadratic(self.Qc, self.A, self.B, self.Cv)
+
+    def constraints_hessian(self, x=None, u=None):
+        n, m = self.N, self.M
+        return [2.0 * q for q in self.Qc], [np.zeros((m, m))] * self.C, [np.zeros((n, m))] * self.C
+
+
+def _quadratic(n, m, c):
+    return type(f"QuadraticConstraints{n}_{m}_{c}", (_QuadraticConstraints,), dict(N=n, M=m, C=c))
+
+
 def _linear(n, m, c):
     return type(f"LinearConstraints{n}_{m}_{c}", (_LinearConstraints,), dict(N=n, M=m, C=c))
 
@@ -138,6 +169,8 @@ LinearConstraints4_1_10 = _linear(4, 1, 10)
 LinearConstraints4_1_6 = _linear(4, 1, 6)
 BoxConstraints6_2 = _box(6, 2)
 BoxConstraints4_1 = _box(4, 1)
+QuadraticConstraints6_2_5 = _quadratic(6, 2, 5)
+QuadraticConstraints4_1_3 = _quadratic(4, 1, 3)
 
 
 class _Node:
@@ -185,7 +218,7 @@ class _Node:
     # ---- node maths: one node through the parallel-in-time kernel ----
     def _eval(self, state, control):
         c = self.constraints_obj
-        desc = capi.make_problem(self.MODEL, "new_al", 1, 1, self.L, self.dt, v=self.v, k=self.k, c=c.C)
+        desc = capi.make_problem(self.MODEL, "new_al", 1, 1, self.L, self.dt, v=self.v, k=self.k, c=c.C, cons_kind=c.KIND)
         x = np.zeros((1, 2, self.N)); x[0, 0] = _vec(state, self.N, "state")
         u = np.zeros((1, 2, self.M)); u[0, 0] = _vec(control, self.M, "control")
         lam = np.zeros((1, 2, c.C)); lam[0, 0] = c.lambda_
@@ -236,6 +269,8 @@ NewBicycleNodeLinearConstraints6_2_16 = _bicycle_node(LinearConstraints6_2_16)
 NewLatBicycleNodeLinearConstraints4_1_6 = _lat_node(LinearConstraints4_1_6)
 NewLatBicycleNodeLinearConstraints4_1_10 = _lat_node(LinearConstraints4_1_10)
 NewLatBicycleNodeBoxConstraints4_1 = _lat_node(BoxConstraints4_1)
+NewBicycleNodeQuadraticConstraints6_2_5 = _bicycle_node(QuadraticConstraints6_2_5)
+NewLatBicycleNodeQuadraticConstraints4_1_3 = _lat_node(QuadraticConstraints4_1_3)
 
 
 class _NewALILQR:
@@ -274,7 +309,7 @@ class _NewALILQR:
         prm.max_outer, prm.max_inner = int(max_outer_iter), int(max_inner_iter)
         prm.viol_stop, prm.viol_lambda = float(max_violation), 5.0 * float(max_violation)   # new_al_ilqr.h:1198-1211
         desc = capi.make_problem(type(nd0).MODEL, "new_al", self.horizon, B, nd0.L, nd0.dt, v=nd0.v, k=nd0.k,
-                                 c=nd0.constraints_obj.C, table_nodes=tn, params=prm)
+                                 c=nd0.constraints_obj.C, table_nodes=tn, params=prm, cons_kind=nd0.constraints_obj.KIND)
         goals = np.stack([nd.goal() for nd in nodes])[None]
         return desc, goals, Q, R, T
 

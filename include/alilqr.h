@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ALILQR_ABI_VERSION 1
+#define ALILQR_ABI_VERSION 2
 
 /* ---- vehicle model (node type) ------------------------------------------
  * LAT      4 states / 1 control   cilqr/lat_bicycle_node.py:4-91
@@ -50,6 +50,17 @@ enum alilqr_mode {
   ALILQR_MODE_LEGACY = 0,
   ALILQR_MODE_FAST = 1,
   ALILQR_MODE_NEW_AL = 2
+};
+
+/* ---- constraint table kind -------------------------------------------------
+ * LINEAR     c(x,u) = A x + B u + C                 linear_constraints.py:13-29, al_ilqr_cpp/constraints/linear_constraints.h
+ *            (LEGACY ignores the field: its table is the box  state_min | state_max | control_min | control_max)
+ * QUADRATIC  c_i(x,u) = x' Qc_i x + A_i x + B_i u + C_i      al_ilqr_cpp/constraints/quadratic_constraints.h:6-98
+ *            (NEW_AL only; the circle obstacles of test_new_al_ilqr.cc:208-266, test_pybind.py:284-348)
+ */
+enum alilqr_cons_kind {
+  ALILQR_CONS_LINEAR = 0,
+  ALILQR_CONS_QUADRATIC = 1
 };
 
 enum alilqr_status {
@@ -92,6 +103,8 @@ typedef struct alilqr_problem {
   int32_t batch;         /* B problems */
   int32_t goal_batch;    /* 1: all problems track the same goals; B: one goal list each */
   int32_t table_nodes;   /* 1: Q,R,constraint table shared by all nodes; H+1: one per node */
+  int32_t cons_kind;     /* enum alilqr_cons_kind */
+  int32_t reserved;      /* 0 */
   double L, dt, v, k;    /* wheel base, step, (lat) speed, understeer factor */
   alilqr_params prm;
 } alilqr_problem;
@@ -130,6 +143,7 @@ int64_t alilqr_workspace_bytes(const alilqr_problem* p);
  *       R      [table_nodes][m][m]       node.R
  *       cons   [table_nodes][...]        LEGACY: state_min[n] state_max[n] control_min[m] control_max[m]
  *                                        FAST / NEW_AL: A[c][n] B[c][m] C[c]  (c(x,u) = A x + B u + C <= 0)
+ *                                        NEW_AL, cons_kind QUADRATIC: A[c][n] B[c][m] C[c] Qc[c][n][n]
  *  out  x_out  [B][H+1][n], u_out [B][H][m]      the (x, u) pair optimize() returns
  *       node_x [B][H+1][n], node_u [B][H][m]     node.state / node.control after optimize() (may be NULL)
  *       x_init [B][H+1][n], u_init [B][H][m]     the initial guess optimize() also returns (may be NULL)

@@ -10,8 +10,8 @@
  * by review against the cited lines and by the node / constraint formulas it
  * shares with the Python generations (tests compare those).
  *
- * Not restated (the reference paths marked "next"): quadratic constraints,
- * rectangle-obstacle activation (UpdateConstraints), equality constraints.
+ * Not restated (the reference paths marked "next"): rectangle-obstacle
+ * activation (UpdateConstraints), equality constraints.
  */
 #define _GNU_SOURCE   /* M_PI under -std=c11 */
 #include "alilqr_oracle.h"
@@ -27,10 +27,12 @@ typedef struct nw_node {
   int model, n, m, c;
   double L, dt, v, k;
   const double *Q, *R, *A, *B, *C;
+  const double* Qc;                    /* quadratic table: c matrices n x n, or NULL (quadratic_constraints.h:94) */
   double goal[OR_NX];
   double lam[OR_NC], mu;
   /* caches of constraints.h: c_, lambda_proj_, dxdx_, dudu_ */
   double c_[OR_NC], lp_[OR_NC], dxdx[OR_NX * OR_NX], dudu[OR_NU * OR_NU];
+  double cx_[OR_NC * OR_NX];           /* constraint Jacobian wrt x at the last cost_jacobian() point */
 } nw_node;
 
 /* model/new_ilqr_node.h:32-37 — identity inside (-pi, pi), C fmod (sign of the dividend) outside */
@@ -188,13 +190,36 @@ static void nw_fxx(const nw_node* nd, const double* s, const double* uc, double*
   H2[4 * 6 + 4] = dt * 2 * k * v * (kv2 - 3) * td / L / kp1 / kp1 / kp1;
 }
 
-/* linear_constraints.h:176-181 */
+/* x' Q_i x as (x' Q_i) x  (quadratic_constraints.h:21-24) */
+static double nw_quad_term(const nw_node* nd, int i, const double* x) {
+  int n = nd->n;
+  const double* Qi = nd->Qc + (size_t)i * n * n;
+  double q = 0.0;
+  for (int j = 0; j < n; ++j) {
+    double t = 0.0;
+    for (int k = 0; k < n; ++k) t += x[k] * Qi[k * n + j];
+    q += t * x[j];
+  }
+  return q;
+}
+/* linear_constraints.h:176-181 ; quadratic_constraints.h:15-27 (quadratic term first in the sum) */
 static void nw_constraints(const nw_node* nd, const double* x, const double* u, double* c) {
   for (int i = 0; i < nd->c; ++i) {
     double ax = 0.0, bu = 0.0;
     for (int j = 0; j < nd->n; ++j) ax += nd->A[i * nd->n + j] * x[j];
     for (int j = 0; j < nd->m; ++j) bu += nd->B[i * nd->m + j] * u[j];
+    if (nd->Qc) c[i] = ((nw_quad_term(nd, i, x) + ax) + bu) + nd->C[i];
+    else c[i] = ax + bu + nd->C[i];
+  }
+}
+/* one column of parallel_constraints: linear_constraints.h ; quadratic_constraints.h:29-45 (quadratic term last) */
+static void nw_par_constraints(const nw_node* nd, const double* x, const double* u, double* c) {
+  for (int i = 0; i < nd->c; ++i) {
+    double ax = 0.0, bu = 0.0;
+    for (int j = 0; j < nd->n; ++j) ax += nd->A[i * nd->n + j] * x[j];
+    for (int j = 0; j < nd->m; ++j) bu += nd->B[i * nd->m + j] * u[j];
     c[i] = ax + bu + nd->C[i];
+    if (nd->Qc) c[i] = c[i] + nw_quad_term(nd, i, x);
   }
 }
 /* constraints.h:514-529 */
@@ -227,7 +252,7 @@ static double nw_par_cost(const nw_node* nd, const double* x, const double* u) {
     cq += e * (e * nd->Q[i * nd->n + i]);
   }
   for (int j = 0; j < nd->m; ++j) cr += (nd->R[j * nd->m + j] * u[j]) * u[j];
-  nw_constraints(nd, x, u, c);
+  nw_par_constraints(nd, x, u, c);
   for (int i = 0; i < nd->c; ++i) {
     double p = fmin(nd->lam[i] - nd->mu * c[i], 0.0);
     al += p * p - nd->lam[i] * nd->lam[i];
@@ -248,10 +273,22 @@ static void nw_cost_jacobian(nw_node* nd, const double* x, const double* u, doub
     for (int j = 0; j < m; ++j) s += (2 * nd->R[i * m + j]) * u[j];
     Ju[i] = s;
   }
+  /* c_x = A (+ rows 2 Q_i x, quadratic_constraints.h:47-55) */
+  for (int i = 0; i < nd->c; ++i)
+    for (int a = 0; a < n; ++a) {
+      double v = nd->A[i * n + a];
+      if (nd->Qc) {
+        const double* Qi = nd->Qc + (size_t)i * n * n;
+        double qx = 0.0;
+        for (int k = 0; k < n; ++k) qx += (2 * Qi[a * n + k]) * x[k];
+        v = v + qx;
+      }
+      nd->cx_[i * n + a] = v;
+    }
   /* columns of cx^T / cu^T are zeroed where lambda_proj >= 0 (projection_jacobian2, constraints.h:429-436) */
   for (int a = 0; a < n; ++a) {
     double s = 0.0;
-    for (int i = 0; i < nd->c; ++i) s += ((nd->lp_[i] >= 0.0) ? 0.0 : nd->A[i * n + a]) * nd->lp_[i];
+    for (int i = 0; i < nd->c; ++i) s += ((nd->lp_[i] >= 0.0) ? 0.0 : nd->cx_[i * n + a]) * nd->lp_[i];
     Jx[a] += -s;
   }
   for (int a = 0; a < m; ++a) {
@@ -262,7 +299,7 @@ static void nw_cost_jacobian(nw_node* nd, const double* x, const double* u, doub
   for (int a = 0; a < n; ++a)
     for (int b = 0; b < n; ++b) {
       double s = 0.0;
-      for (int i = 0; i < nd->c; ++i) s += (nd->mu * ((nd->lp_[i] >= 0.0) ? 0.0 : nd->A[i * n + a])) * nd->A[i * n + b];
+      for (int i = 0; i < nd->c; ++i) s += (nd->mu * ((nd->lp_[i] >= 0.0) ? 0.0 : nd->cx_[i * n + a])) * nd->cx_[i * n + b];
       nd->dxdx[a * n + b] = s;
     }
   for (int a = 0; a < m; ++a)
@@ -272,10 +309,16 @@ static void nw_cost_jacobian(nw_node* nd, const double* x, const double* u, doub
       nd->dudu[a * m + b] = s;
     }
 }
-/* new_bicycle_node.h:897-910 + constraints.h:773-816 (zero constraint Hessians for linear tables) */
+/* new_bicycle_node.h:897-910 + constraints.h:773-816: H -= sum_i lambda_proj_i * (2 Q_i)  (tensor_contract :1319-1347);
+ * the constraint Hessians of a linear table are zero */
 static void nw_cost_hessian(nw_node* nd, double* Hx, double* Hu) {
   int n = nd->n, m = nd->m;
-  for (int i = 0; i < n * n; ++i) Hx[i] = 2 * nd->Q[i] + (nd->dxdx[i] - 1.0 * 0.0);
+  for (int i = 0; i < n * n; ++i) {
+    double t = 0.0;
+    if (nd->Qc)
+      for (int r = 0; r < nd->c; ++r) t += (2.0 * nd->Qc[(size_t)r * n * n + i]) * nd->lp_[r];
+    Hx[i] = 2 * nd->Q[i] + (nd->dxdx[i] - 1.0 * t);
+  }
   for (int i = 0; i < m * m; ++i) Hu[i] = 2 * nd->R[i] + (nd->dudu[i] - 1.0 * 0.0);
 }
 /* constraints.h:1027-1040 */
@@ -304,8 +347,10 @@ static void nw_node_init(nw_node* nd, const alilqr_problem* p, int t,
   nd->L = p->L; nd->dt = p->dt; nd->v = p->v; nd->k = p->k;
   nd->Q = Q + (size_t)tt * n * n;
   nd->R = R + (size_t)tt * m * m;
-  const double* b = cons + (size_t)tt * (c * n + c * m + c);
+  const int quad = (p->cons_kind == ALILQR_CONS_QUADRATIC);
+  const double* b = cons + (size_t)tt * (c * n + c * m + c + (quad ? c * n * n : 0));
   nd->A = b; nd->B = b + c * n; nd->C = b + c * n + c * m;
+  nd->Qc = quad ? b + c * n + c * m + c : NULL;
   memcpy(nd->goal, goals + (size_t)t * n, sizeof(double) * n);
   nd->mu = 1.0;
 }

@@ -102,3 +102,35 @@ def test_pybind_shaped_solver_runs_the_reference_script_flow():
     assert gu.rel_err(f, x[:, 1]) < 1e-14
     fx, fu = nodes[0].dynamics_jacobian(x[:, 0], u[:, 0])
     assert fx.shape == (6, 6) and fu.shape == (6, 2)
+
+
+def test_pybind_shaped_quadratic_constraints_flow():
+    """Second half of cilqr/test_pybind.py:284-348: a circle obstacle as QuadraticConstraints6_2_5 with control
+    bounds 0.4 / 1, optimize(50, 100, 1e-4).  The script's circle (30, 11) r = 6 gives a solve the oracle does not
+    reproduce from a start moved by 1e-13; the circle used here, (25, 12) r = 3, gives one it reproduces to 1e-9, so the
+    1e-6 comparison means something."""
+    import oracle_lib as ol
+    from ilqr_amd import problems, pybind_api as ip
+    v, dt, L, k, H = 10.0, 0.1, 3.0, 0.001, 30
+    goals = problems.s_curve_goals(v, dt, H, True)
+    Q = np.diag([1e-1, 1e-1, 1e-0, 1e-9, 1e-6, 1e-6]) * 1e3
+    R = np.diag([1.0, 1.0]) * 1e2
+    Qc, Ac, Cc = problems.circle_rows(25.0, 12.0, 3.0, 6)
+    Q_list = [Qc] + [np.zeros((6, 6))] * 4
+    A = np.zeros((5, 6)); A[0] = Ac
+    B = np.array([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], dtype=float)
+    C = np.array([[Cc], [-0.4], [-1], [-0.4], [-1]], dtype=float)
+    cons = ip.QuadraticConstraints6_2_5(Q_list, A, B, C)
+    nodes = [ip.NewBicycleNodeQuadraticConstraints6_2_5(L, dt, k, goals[i], Q, R, cons) for i in range(H + 1)]
+    x0 = np.array([0, 0, 0, 0, v, 0.0])
+    s = ip.NewALILQR6_2(nodes, x0)
+    s.optimize(50, 100, 1e-4)
+    x = s.get_x_list()
+    desc, g, Qt, Rt, T = s._describe(1, 50, 100, 1e-4)
+    assert desc.cons_kind == 1 and T.shape[-1] == 5 * (6 + 2 + 1) + 5 * 36
+    ref = ol.solve_batch(desc, x0[None], g, Qt, Rt, T)
+    assert s.last_status["inner"] == ref["status"][0, 0]
+    assert gu.rel_err(x.T, ref["x"][0]) < 1e-6 and gu.rel_err(s.get_u_list().T, ref["u"][0]) < 1e-6
+    # (the goal curve runs through the centre of this circle, where the constraint gradient vanishes: the
+    #  algorithm, in the oracle as here, ends at the outer-iteration cap without leaving it — not asserted)
+    assert s.last_status["outer"] == ref["status"][0, 1]

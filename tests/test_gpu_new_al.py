@@ -43,7 +43,11 @@ SETS = {
     "box6_h30": lambda B: problems.new_al_box(B, H=30, seed=9),
     "box6_active_bound": lambda B: problems.new_al_box(B, y_max=20.0),
     "lat4": lambda B: problems.new_al_lat(B),
+    "circle6": lambda B: problems.new_al_circle(B),            # quadratic rows (quadratic_constraints.h)
+    "circle4": lambda B: problems.new_al_lat_circle(B),
 }
+# fraction of solves the oracle must reproduce from a 1e-13-perturbed start (the rest are not comparable)
+FLOOR = {"box6": 0.8, "box6_h30": 0.8, "lat4": 0.8, "box6_active_bound": 0.25, "circle6": 0.4, "circle4": 0.1}
 
 
 @pytest.mark.parametrize("lanes", ["auto", "1", "4", "32"])
@@ -56,8 +60,7 @@ def test_new_al_matches_oracle(name, lanes, monkeypatch):
     ref = ol.solve_batch(desc, x0, goals, Q, R, cons)
     o = to_np(batch.solve_batch(desc, x0, goals, Q, R, cons))
     ok = stable_mask(desc, x0, goals, Q, R, cons, ref)
-    floor = 0.25 if name == "box6_active_bound" else 0.8
-    assert ok.mean() >= floor, (name, ok.mean())
+    assert ok.mean() >= FLOOR[name], (name, ok.mean())
     for i in np.nonzero(ok)[0]:
         assert worst_err(o, ref, i) < TOL, (name, i, o["status"][i], ref["status"][i])
     assert gu.rel_err(o["x_init"], ref["x_init"]) < 1e-12
@@ -66,7 +69,8 @@ def test_new_al_matches_oracle(name, lanes, monkeypatch):
     # properties every solve must have, stable or not
     fin = np.isfinite(o["cost"])
     assert np.array_equal(o["x"][:, 0], x0)
-    assert ((o["status"][:, 2] & capi.FLAG_VIOL_OK) != 0)[fin].mean() > 0.5
+    if not name.startswith("circle4"):      # the lateral circle demo mostly ends at the outer cap, in the oracle too
+        assert ((o["status"][:, 2] & capi.FLAG_VIOL_OK) != 0)[fin].mean() > 0.5
     conv = (o["status"][:, 2] & capi.FLAG_VIOL_OK) != 0
     assert np.all(o["viol"][conv] < desc.prm.viol_stop)
 
@@ -95,8 +99,9 @@ def test_new_al_returned_pair_is_consistent():
     assert gu.rel_err(lin["l"].sum(axis=1), o["cost"]) < 1e-12
 
 
+@pytest.mark.parametrize("quad", [False, True])
 @pytest.mark.parametrize("model", ["new_bicycle", "lat_k"])
-def test_new_al_node_kernel_matches_oracle(model):
+def test_new_al_node_kernel_matches_oracle(model, quad):
     rng = np.random.default_rng(5)
     N = 200
     n, m = (6, 2) if model == "new_bicycle" else (4, 1)
@@ -109,12 +114,19 @@ def test_new_al_node_kernel_matches_oracle(model):
     LAM = -np.abs(rng.normal(size=(N, c))); LAM[rng.uniform(size=(N, c)) < 0.3] = 0.0
     MU = 10.0 ** rng.uniform(0, 4, size=N)
     Q = np.diag(rng.uniform(0.1, 10, size=n)); R = np.diag(rng.uniform(0.1, 10, size=m))
-    desc = capi.make_problem(model, "new_al", 1, N, 3.0, 0.1, v=10.0, k=0.001, c=c)
+    desc = capi.make_problem(model, "new_al", 1, N, 3.0, 0.1, v=10.0, k=0.001, c=c,
+                             cons_kind=capi.CONS_QUADRATIC if quad else capi.CONS_LINEAR)
     goals = np.tile(rng.normal(size=n), (2, 1))
     x = np.zeros((N, 2, n)); x[:, 0] = X
     u = np.zeros((N, 2, m)); u[:, 0] = U
     lam = np.zeros((N, 2, c)); lam[:, 0] = LAM
-    cons = capi.pack_linear(A, Bm, Cv)
+    if quad:
+        Qc = rng.normal(size=(c, n, n)) * 0.01
+        Qc[2] = 0.0                                     # a row without a quadratic term
+        Qc[4] = 0.5 * (Qc[4] + Qc[4].T)
+        cons = capi.pack_quadratic(Qc, A, Bm, Cv)
+    else:
+        cons = capi.pack_linear(A, Bm, Cv)
     ref = ol.linearize_batch(desc, x, u, lam, MU, goals, Q, R, cons)
     o = to_np(batch.linearize_batch(desc, x, u, lam, MU, goals, Q, R, cons))
     for key in ("f", "fx", "fu", "l", "lx", "lu", "lxx", "luu"):

@@ -108,3 +108,53 @@ def test_new_lat_node_with_zero_understeer_is_the_python_lateral_model():
                              capi.pack_linear(A, Bm, Cv))
     for key in ("f", "fx", "fu"):
         assert gu.rel_err(out[key][:, 0], k[pre + key][keep]) < 1e-12, key
+
+
+def test_quadratic_constraint_derivatives_are_consistent():
+    """Circle-obstacle rows (quadratic_constraints.h:15-91): the oracle's l_x, l_u must be the gradient of its own
+    cost and l_xx, l_uu the Hessian of it (for a fixed active set the AL Hessian mu (P c_x)' c_x - sum lp_i 2Q_i is
+    exact), checked by central differences at points inside, on the edge of and outside the circle."""
+    rng = np.random.default_rng(11)
+    desc, _, goals, Q, R, cons = problems.new_al_circle(1, H=1)
+    pts = np.array([[20.5, 12.3, 0.2, 0.05, 9.0, 0.1], [16.1, 12.0, -0.3, 0.0, 10.0, 0.0], [5.0, 3.0, 0.1, 0.0, 11.0, -0.2]])
+    N = pts.shape[0]
+    d = capi.make_problem("new_bicycle", "new_al", 1, N, desc.L, desc.dt, k=desc.k, c=desc.c, cons_kind=capi.CONS_QUADRATIC)
+    lam = np.zeros((N, 2, desc.c)); lam[:, 0] = -rng.uniform(0, 2, size=(N, desc.c))
+    mu = np.array([3.0, 50.0, 7.0])
+    U = np.array([[0.25, 0.5], [-0.1, 1.2], [0.0, 0.0]])
+
+    def ev(X, Uc):
+        x = np.zeros((N, 2, 6)); x[:, 0] = X
+        u = np.zeros((N, 2, 2)); u[:, 0] = Uc
+        return ol.linearize_batch(d, x, u, lam, mu, goals, Q, R, cons)
+
+    base = ev(pts, U)
+    # the circle row is active at the inside point, inactive far outside
+    assert base["cval"][0, 0, 0] > 0 and base["cval"][2, 0, 0] < 0
+    h = 1e-5
+    for j in range(6):
+        dx = np.zeros(6); dx[j] = h
+        p, m_ = ev(pts + dx, U), ev(pts - dx, U)
+        fd = (p["l"][:, 0] - m_["l"][:, 0]) / (2 * h)
+        assert np.allclose(fd, base["lx"][:, 0, j], rtol=1e-6, atol=1e-4 * np.abs(base["lx"][:, 0]).max())
+        fdh = (p["lx"][:, 0] - m_["lx"][:, 0]) / (2 * h)
+        assert np.allclose(fdh, base["lxx"][:, 0, :, j], rtol=1e-5, atol=1e-6 * np.abs(base["lxx"][:, 0]).max())
+    for j in range(2):
+        du = np.zeros(2); du[j] = h
+        p, m_ = ev(pts, U + du), ev(pts, U - du)
+        fd = (p["l"][:, 0] - m_["l"][:, 0]) / (2 * h)
+        assert np.allclose(fd, base["lu"][:, 0, j], rtol=1e-6, atol=1e-4 * max(1.0, np.abs(base["lu"][:, 0]).max()))
+        fdh = (p["lu"][:, 0] - m_["lu"][:, 0]) / (2 * h)
+        assert np.allclose(fdh, base["luu"][:, 0, :, j], rtol=1e-5, atol=1e-6 * np.abs(base["luu"][:, 0]).max())
+    # value of the circle row by hand: r^2 - (x-cx)^2 - (y-cy)^2
+    assert np.allclose(base["cval"][:, 0, 0], 16.0 - (pts[:, 0] - 20.0) ** 2 - (pts[:, 1] - 12.0) ** 2, rtol=1e-12)
+
+
+def test_reference_circle_demo_converges_and_clears_the_obstacle():
+    """al_ilqr_cpp/test_new_al_ilqr.cc:208-266: circle (20, 12) r = 4, optimize(30, 100, 1e-3)."""
+    desc, _, goals, Q, R, cons = problems.new_al_circle(1)
+    out = ol.solve_batch(desc, np.array([[0.0, 0.0, 0.0, 0.0, 10.0, 0.0]]), goals, Q, R, cons)
+    assert out["status"][0, 2] == capi.FLAG_VIOL_OK and out["viol"][0] < 1e-3
+    dist = np.hypot(out["x"][0, :, 0] - 20.0, out["x"][0, :, 1] - 12.0)
+    assert dist.min() > 4.0 - 1e-3          # the goal curve itself passes 1.7 m from the centre
+    assert np.hypot(goals[:, 0] - 20.0, goals[:, 1] - 12.0).min() < 2.0

@@ -11,7 +11,8 @@ def main():
     sets = {"new_box": lambda: problems.new_al_box(B), "new_lat": lambda: problems.new_al_lat(B),
             "new_box_active": lambda: problems.new_al_box(B, y_max=20.0),
             "lat_legacy": lambda: problems.lat_legacy(B), "fast_box": lambda: problems.fast_box(B),
-            "dyn_legacy": lambda: problems.full_legacy("dyn", B, 60, 3)}
+            "dyn_legacy": lambda: problems.full_legacy("dyn", B, 60, 3),
+            "circle6": lambda: problems.new_al_circle(B), "lat_circle": lambda: problems.new_al_lat_circle(B)}
     desc, x0, goals, Q, R, cons = sets[name]()
     with open(out, "wb") as f:
         f.write(bytes(desc))
