@@ -35,12 +35,15 @@ def _require_gpu(device):
     return torch.device(device)
 
 
-def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=True, u_offset=None):
+def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=True, u_offset=None,
+                left_obs=None, right_obs=None, first_row=0):
     """Solve ``desc.batch`` problems on the GPU.
 
     Inputs may be numpy arrays or torch tensors (moved to ``device`` as fp64):
       x0 [B,n], goals [goal_batch,H+1,n], Q [T,n,n], R [T,m,m], cons [T,words].
     ``u_offset`` [B,H,m] (optional) perturbs the controls of the initial guess: B starts of one scenario.
+    ``left_obs`` / ``right_obs`` (optional, NEW_AL): lists of 2x4 rectangle vertex matrices whose y-bounds are
+    written into the nodes' constraint tables while the solve runs; ``first_row`` is the row index the nodes start from.
     Returns a dict of device tensors: x [B,H+1,n], u [B,H,m], cost [B] and, with
     ``extras``, node_x, node_u, x_init, u_init, viol, lam, mu, status.
     """
@@ -62,6 +65,11 @@ def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=
         uo_d = _dev_f64(u_offset, dev)
         if uo_d.numel() != B * H * m:
             raise ValueError("u_offset must hold batch*H*m values")
+    lo, ro = capi.pack_rectangles(left_obs), capi.pack_rectangles(right_obs)
+    lo_d = _dev_f64(lo, dev) if len(lo) else None
+    ro_d = _dev_f64(ro, dev) if len(ro) else None
+    ex = capi.Extras(None if uo_d is None else uo_d.data_ptr(), None if lo_d is None else lo_d.data_ptr(),
+                     None if ro_d is None else ro_d.data_ptr(), len(lo), len(ro), int(first_row), 0)
     f64 = dict(dtype=torch.float64, device=dev)
     out = dict(x=torch.empty((B, H + 1, n), **f64), u=torch.empty((B, H, m), **f64), cost=torch.empty((B,), **f64))
     if extras:
@@ -71,12 +79,12 @@ def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=
                    status=torch.zeros((B, capi.STATUS_WORDS), dtype=torch.int32, device=dev))
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
-        rc = lib.alilqr_solve_batch_multistart(C.byref(desc), _ptr(x0_d), _ptr(goals_d), _ptr(Q_d), _ptr(R_d), _ptr(cons_d),
-                                    _ptr(uo_d), _ptr(out["x"]), _ptr(out["u"]), _ptr(out.get("node_x")), _ptr(out.get("node_u")),
+        rc = lib.alilqr_solve_batch_ex(C.byref(desc), _ptr(x0_d), _ptr(goals_d), _ptr(Q_d), _ptr(R_d), _ptr(cons_d),
+                                    C.byref(ex), _ptr(out["x"]), _ptr(out["u"]), _ptr(out.get("node_x")), _ptr(out.get("node_u")),
                                     _ptr(out.get("x_init")), _ptr(out.get("u_init")), _ptr(out["cost"]),
                                     _ptr(out.get("viol")), _ptr(out.get("lam")), _ptr(out.get("mu")),
                                     _ptr(out.get("status")), C.c_void_p(stream))
-        capi.check(rc, "alilqr_solve_batch_multistart")
+        capi.check(rc, "alilqr_solve_batch_ex")
         if sync:
             torch.cuda.synchronize(dev)
     return out

@@ -41,6 +41,22 @@ class Problem(C.Structure):
                 ("prm", Params)]
 
 
+class Extras(C.Structure):
+    """struct alilqr_extras (pointers are device pointers for the HIP library, host pointers for the test oracle)"""
+    _fields_ = [("u_offset", C.c_void_p), ("left_obs", C.c_void_p), ("right_obs", C.c_void_p),
+                ("n_left", C.c_int32), ("n_right", C.c_int32), ("first_row", C.c_int32), ("reserved", C.c_int32)]
+
+
+def pack_rectangles(rects):
+    """List of 2x4 vertex matrices (x row, y row; counter-clockwise) -> contiguous [n][2][4] array."""
+    if rects is None or len(rects) == 0:
+        return np.zeros((0, 2, 4))
+    a = np.ascontiguousarray(np.stack([np.asarray(r, dtype=np.float64) for r in rects]))
+    if a.shape[1:] != (2, 4):
+        raise TypeError("every rectangle is a 2x4 matrix of vertex coordinates")
+    return a
+
+
 def default_params(mode):
     """Reference literals per solver generation (ilqr.py:151-174, fast_ilqr.py:136-159,
     new_al_ilqr.h:1177-1211)."""
@@ -113,7 +129,8 @@ _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libalilqr_hip.so")
 
 EXPORTS = ("alilqr_abi_version", "alilqr_last_error", "alilqr_device_count", "alilqr_default_params",
-           "alilqr_workspace_bytes", "alilqr_solve_batch", "alilqr_solve_batch_multistart", "alilqr_linearize_batch",
+           "alilqr_workspace_bytes", "alilqr_solve_batch", "alilqr_solve_batch_multistart", "alilqr_solve_batch_ex",
+           "alilqr_linearize_batch",
            "alilqr_release")
 
 
@@ -147,6 +164,8 @@ def load_library():
     lib.alilqr_solve_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17
     lib.alilqr_solve_batch_multistart.restype = C.c_int32
     lib.alilqr_solve_batch_multistart.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 18
+    lib.alilqr_solve_batch_ex.restype = C.c_int32
+    lib.alilqr_solve_batch_ex.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 5 + [C.POINTER(Extras)] + [C.c_void_p] * 12
     lib.alilqr_linearize_batch.restype = C.c_int32
     lib.alilqr_linearize_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17
     lib.alilqr_release.restype = C.c_int32

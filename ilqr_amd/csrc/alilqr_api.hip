@@ -113,7 +113,14 @@ struct Plan {
   size_t trj, blk, ucum, counter, total;   // byte offsets / total
 };
 
-size_t block_doubles_for(const alilqr_problem* p) {
+// kernel instantiation of a NEW_AL descriptor: constraint kind x rectangle activation
+int new_al_variant(const alilqr_problem* p, bool rect) {
+  const bool quad = (p->cons_kind == ALILQR_CONS_QUADRATIC);
+  if (quad) return rect ? alilqr::kModeNewAlQuadRect : alilqr::kModeNewAlQuad;
+  return rect ? alilqr::kModeNewAlRect : ALILQR_MODE_NEW_AL;
+}
+
+size_t block_doubles_for(const alilqr_problem* p, bool rect) {
   using namespace alilqr;
   const int H = p->horizon, C = p->c;
   if (p->mode == ALILQR_MODE_LEGACY) {
@@ -121,13 +128,15 @@ size_t block_doubles_for(const alilqr_problem* p) {
     return block_doubles<Model<ALILQR_MODEL_KIN>, ALILQR_MODE_LEGACY>(H, C);
   }
   if (p->mode == ALILQR_MODE_NEW_AL) {
-    if (p->model == ALILQR_MODEL_LAT_K) return block_doubles<Model<ALILQR_MODEL_LAT_K>, ALILQR_MODE_NEW_AL>(H, C);
-    return block_doubles<Model<ALILQR_MODEL_NEW_BICYCLE>, ALILQR_MODE_NEW_AL>(H, C);
+    // the record layout depends on the rectangle overlay only
+    if (p->model == ALILQR_MODEL_LAT_K)
+      return rect ? block_doubles<Model<ALILQR_MODEL_LAT_K>, kModeNewAlRect>(H, C) : block_doubles<Model<ALILQR_MODEL_LAT_K>, ALILQR_MODE_NEW_AL>(H, C);
+    return rect ? block_doubles<Model<ALILQR_MODEL_NEW_BICYCLE>, kModeNewAlRect>(H, C) : block_doubles<Model<ALILQR_MODEL_NEW_BICYCLE>, ALILQR_MODE_NEW_AL>(H, C);
   }
   return block_doubles<Model<ALILQR_MODEL_DYN_MID>, ALILQR_MODE_FAST>(H, C);
 }
 
-Plan make_plan(const alilqr_problem* p, const Dims& d) {
+Plan make_plan(const alilqr_problem* p, const Dims& d, bool rect = false) {
   Plan pl{};
   pl.G = pick_group(p);
   long max_waves = 4096;
@@ -145,7 +154,7 @@ Plan make_plan(const alilqr_problem* p, const Dims& d) {
   const size_t SS = (p->mode == ALILQR_MODE_LEGACY) ? alilqr::TrjSlots<ALILQR_MODE_LEGACY>::SS : alilqr::TrjSlots<ALILQR_MODE_FAST>::SS;
   pl.trj = off; off = up(off + sizeof(double) * 2 * T * (size_t)pl.NG * SS);
   pl.ucum = off; off = up(off + sizeof(double) * H * M * (size_t)pl.NG * pl.G);
-  pl.blk = off; off = up(off + sizeof(double) * block_doubles_for(p) * (size_t)pl.NG);
+  pl.blk = off; off = up(off + sizeof(double) * block_doubles_for(p, rect) * (size_t)pl.NG);
   pl.total = off;
   return pl;
 }
@@ -270,7 +279,8 @@ int64_t alilqr_workspace_bytes(const alilqr_problem* p) {
   Dims d;
   int32_t rc = check_problem(p, &d);
   if (rc != ALILQR_OK) return rc;
-  return (int64_t)make_plan(p, d).total;
+  /* NEW_AL: sized for a solve with rectangle obstacles (the larger record) */
+  return (int64_t)make_plan(p, d, p->mode == ALILQR_MODE_NEW_AL).total;
 }
 
 int32_t alilqr_solve_batch(const alilqr_problem* p,
@@ -296,6 +306,31 @@ int32_t alilqr_solve_batch_multistart(const alilqr_problem* p,
                                       double* cost, double* viol,
                                       double* lam, double* mu,
                                       int32_t* status, void* stream) {
+  alilqr_extras ex{};
+  ex.u_offset = u_offset;
+  return alilqr_solve_batch_ex(p, x0, goals, Q, R, cons, &ex, x_out, u_out, node_x, node_u, x_init, u_init,
+                               cost, viol, lam, mu, status, stream);
+}
+
+int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
+                              const double* x0, const double* goals,
+                              const double* Q, const double* R, const double* cons,
+                              const alilqr_extras* ex,
+                              double* x_out, double* u_out,
+                              double* node_x, double* node_u,
+                              double* x_init, double* u_init,
+                              double* cost, double* viol,
+                              double* lam, double* mu,
+                              int32_t* status, void* stream) {
+  const double* u_offset = ex ? ex->u_offset : nullptr;
+  const int n_left = ex ? ex->n_left : 0, n_right = ex ? ex->n_right : 0;
+  const bool rect = (n_left > 0) || (n_right > 0);
+  if (ex) {
+    if (n_left < 0 || n_left > 16 || n_right < 0 || n_right > 16) { set_err("n_left, n_right must be 0..16"); return ALILQR_E_ARG; }
+    if ((n_left > 0 && !ex->left_obs) || (n_right > 0 && !ex->right_obs)) { set_err("null rectangle list"); return ALILQR_E_ARG; }
+    if (rect && (!p || p->mode != ALILQR_MODE_NEW_AL)) { set_err("rectangle obstacles are defined for NEW_AL"); return ALILQR_E_ARG; }
+    if (rect && (ex->first_row < 0 || ex->first_row >= p->c)) { set_err("first_row must be a row of the table"); return ALILQR_E_ARG; }
+  }
   Dims d;
   int32_t rc = check_problem(p, &d);
   if (rc != ALILQR_OK) return rc;
@@ -312,7 +347,7 @@ int32_t alilqr_solve_batch_multistart(const alilqr_problem* p,
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDev) { set_err("device index out of range"); return ALILQR_E_ARG; }
   hipStream_t st = (hipStream_t)stream;
-  Plan pl = make_plan(p, d);
+  Plan pl = make_plan(p, d, rect);
   char* base = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -334,6 +369,7 @@ int32_t alilqr_solve_batch_multistart(const alilqr_problem* p,
   ka.quad = (p->cons_kind == ALILQR_CONS_QUADRATIC) ? 1 : 0;
   ka.prm = p->prm;
   ka.x0 = x0; ka.goals = goals; ka.Q = Q; ka.R = R; ka.cons = cons; ka.u_off = u_offset;
+  if (rect) { ka.left_obs = ex->left_obs; ka.right_obs = ex->right_obs; ka.n_left = n_left; ka.n_right = n_right; ka.first_row = ex->first_row; }
   ka.x_out = x_out; ka.u_out = u_out; ka.node_x = node_x; ka.node_u = node_u;
   ka.x_init = x_init; ka.u_init = u_init; ka.cost = cost; ka.viol = viol; ka.lam = lam; ka.mu = mu;
   ka.status = status;
@@ -352,13 +388,23 @@ int32_t alilqr_solve_batch_multistart(const alilqr_problem* p,
   } else if (p->mode == ALILQR_MODE_FAST) {
     if (p->model == ALILQR_MODEL_DYN_MID) return launch_g<ALILQR_MODEL_DYN_MID, ALILQR_MODE_FAST>(ka, pl.G, waves, st);
   } else if (p->mode == ALILQR_MODE_NEW_AL) {
-    const bool quad = (p->cons_kind == ALILQR_CONS_QUADRATIC);
-    if (p->model == ALILQR_MODEL_LAT_K)
-      return quad ? launch_g<ALILQR_MODEL_LAT_K, alilqr::kModeNewAlQuad>(ka, pl.G, waves, st)
-                  : launch_g<ALILQR_MODEL_LAT_K, ALILQR_MODE_NEW_AL>(ka, pl.G, waves, st);
-    if (p->model == ALILQR_MODEL_NEW_BICYCLE)
-      return quad ? launch_g<ALILQR_MODEL_NEW_BICYCLE, alilqr::kModeNewAlQuad>(ka, pl.G, waves, st)
-                  : launch_g<ALILQR_MODEL_NEW_BICYCLE, ALILQR_MODE_NEW_AL>(ka, pl.G, waves, st);
+    const int variant = new_al_variant(p, rect);
+    if (p->model == ALILQR_MODEL_LAT_K) {
+      switch (variant) {
+        case alilqr::kModeNewAlQuad: return launch_g<ALILQR_MODEL_LAT_K, alilqr::kModeNewAlQuad>(ka, pl.G, waves, st);
+        case alilqr::kModeNewAlRect: return launch_g<ALILQR_MODEL_LAT_K, alilqr::kModeNewAlRect>(ka, pl.G, waves, st);
+        case alilqr::kModeNewAlQuadRect: return launch_g<ALILQR_MODEL_LAT_K, alilqr::kModeNewAlQuadRect>(ka, pl.G, waves, st);
+        default: return launch_g<ALILQR_MODEL_LAT_K, ALILQR_MODE_NEW_AL>(ka, pl.G, waves, st);
+      }
+    }
+    if (p->model == ALILQR_MODEL_NEW_BICYCLE) {
+      switch (variant) {
+        case alilqr::kModeNewAlQuad: return launch_g<ALILQR_MODEL_NEW_BICYCLE, alilqr::kModeNewAlQuad>(ka, pl.G, waves, st);
+        case alilqr::kModeNewAlRect: return launch_g<ALILQR_MODEL_NEW_BICYCLE, alilqr::kModeNewAlRect>(ka, pl.G, waves, st);
+        case alilqr::kModeNewAlQuadRect: return launch_g<ALILQR_MODEL_NEW_BICYCLE, alilqr::kModeNewAlQuadRect>(ka, pl.G, waves, st);
+        default: return launch_g<ALILQR_MODEL_NEW_BICYCLE, ALILQR_MODE_NEW_AL>(ka, pl.G, waves, st);
+      }
+    }
   }
   set_err("unsupported model / mode combination");
   return ALILQR_E_ARG;

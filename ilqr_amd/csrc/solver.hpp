@@ -68,6 +68,8 @@ struct KArgs {
   ModelConst mc;
   alilqr_params prm;
   const double *x0, *goals, *Q, *R, *cons;
+  const double *left_obs, *right_obs;   // rectangle obstacles [n][2][4] (NEW_AL row activation), or null
+  int n_left, n_right, first_row;
   const double* u_off;        // optional [B][H][m] added to the controls of the initial guess (multi-start), or null
   double *x_out, *u_out, *node_x, *node_u, *x_init, *u_init, *cost, *viol, *lam, *mu;
   int32_t* status;
@@ -569,12 +571,17 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
 // NEW_AL: the C++ generation (al_ilqr_cpp/constraints/constraints.h:514-1040, model/new_bicycle_node.h:702-910).
 // Same projection-form AL as FAST with three differences: only diag(Q), diag(R) enter the cost, the active-row
 // mask is "projected multiplier < 0" (a row sitting exactly at zero drops out), and the state is not wrapped.
-// Kernel-internal mode value: NEW_AL with quadratic constraint tables.  A separate instantiation keeps the
-// quadratic-row code (and its registers) out of the kernels that solve linear tables.
-constexpr int kModeNewAlQuad = 3;
-__host__ __device__ constexpr bool is_new_al(int mode) { return mode == ALILQR_MODE_NEW_AL || mode == kModeNewAlQuad; }
+// Kernel-internal mode values: NEW_AL with quadratic constraint tables and / or rectangle-obstacle row
+// activation.  Separate instantiations keep that code (and its registers) out of the plain NEW_AL kernels.
+constexpr int kModeNewAlQuad = 3, kModeNewAlRect = 4, kModeNewAlQuadRect = 5;
+__host__ __device__ constexpr bool is_new_al(int mode) { return mode >= ALILQR_MODE_NEW_AL && mode <= kModeNewAlQuadRect; }
+__host__ __device__ constexpr bool is_quad(int mode) { return mode == kModeNewAlQuad || mode == kModeNewAlQuadRect; }
+__host__ __device__ constexpr bool is_rect(int mode) { return mode == kModeNewAlRect || mode == kModeNewAlQuadRect; }
 
-template <int MODEL, bool QUAD>
+// With RECT a node's record carries, behind its C multipliers, an overlay of its constraint table: C row signs
+// (0: row as in the shared table; +-1: row replaced by  sign * y + B_i u + C'_i <= 0), C replacement constants C'_i
+// and the node's row index (LinearConstraints::UpdateConstraints, linear_constraints.h:360-373).
+template <int MODEL, bool QUAD, bool RECT>
 struct NewAlOps {
   using MD = Model<MODEL>;
   static constexpr int N = MD::N, M = MD::M;
@@ -593,26 +600,42 @@ struct NewAlOps {
     }
     return q;
   }
+  // entry j of row i of the node's A, and its C entry, through the overlay
+  __device__ static __forceinline__ double a_ij(const KArgs& a, ctab A, const double* lam, size_t ls, int i, int j) {
+    if (RECT) {
+      const double sgn = lam[(size_t)(a.C + i) * ls];
+      if (sgn != 0.0) return (j == 1) ? sgn : 0.0;
+    }
+    return A[i * N + j];
+  }
+  __device__ static __forceinline__ double c_i(const KArgs& a, ctab Cv, const double* lam, size_t ls, int i) {
+    if (RECT) {
+      if (lam[(size_t)(a.C + i) * ls] != 0.0) return lam[(size_t)(2 * a.C + i) * ls];
+    }
+    return Cv[i];
+  }
   // A x + B u + C (linear_constraints.h:176-181); quadratic tables put x'Qx first in the sum (quadratic_constraints.h:26)
-  __device__ static __forceinline__ double cval(const KArgs& a, ctab tab, const double* x, const double* u, int i) {
+  __device__ static __forceinline__ double cval(const KArgs& a, ctab tab, const double* x, const double* u, int i,
+                                                const double* lam, size_t ls) {
     ctab A = tab, Bm = tab + a.C * N, Cv = tab + a.C * (N + M);
     double ax = 0.0, bu = 0.0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) ax += A[i * N + j] * x[j];
+    for (int j = 0; j < N; ++j) ax += a_ij(a, A, lam, ls, i, j) * x[j];
 #pragma unroll
     for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
-    if (QUAD) return ((quad_term(a, tab, x, i) + ax) + bu) + Cv[i];
-    return ax + bu + Cv[i];
+    if (QUAD) return ((quad_term(a, tab, x, i) + ax) + bu) + c_i(a, Cv, lam, ls, i);
+    return ax + bu + c_i(a, Cv, lam, ls, i);
   }
   // one column of parallel_constraints: the quadratic term comes last (quadratic_constraints.h:44)
-  __device__ static __forceinline__ double par_cval(const KArgs& a, ctab tab, const double* x, const double* u, int i) {
+  __device__ static __forceinline__ double par_cval(const KArgs& a, ctab tab, const double* x, const double* u, int i,
+                                                    const double* lam, size_t ls) {
     ctab A = tab, Bm = tab + a.C * N, Cv = tab + a.C * (N + M);
     double ax = 0.0, bu = 0.0;
 #pragma unroll
-    for (int j = 0; j < N; ++j) ax += A[i * N + j] * x[j];
+    for (int j = 0; j < N; ++j) ax += a_ij(a, A, lam, ls, i, j) * x[j];
 #pragma unroll
     for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
-    double c = ax + bu + Cv[i];
+    double c = ax + bu + c_i(a, Cv, lam, ls, i);
     if (QUAD) c = c + quad_term(a, tab, x, i);
     return c;
   }
@@ -627,7 +650,7 @@ struct NewAlOps {
     double pp = 0.0, ll = 0.0;
     for (int i = 0; i < a.C; ++i) {
       double l = lam[i * ls];
-      double lp = fmin(l - mu * cval(a, tab, x, u, i), 0.0);
+      double lp = fmin(l - mu * cval(a, tab, x, u, i, lam, ls), 0.0);
       pp += lp * lp;
       ll += l * l;
     }
@@ -644,7 +667,7 @@ struct NewAlOps {
     for (int j = 0; j < M; ++j) cr += (R[j * M + j] * u[j]) * u[j];
     for (int i = 0; i < a.C; ++i) {
       double l = lam[i * ls];
-      double pr = fmin(l - mu * par_cval(a, tab, x, u, i), 0.0);
+      double pr = fmin(l - mu * par_cval(a, tab, x, u, i, lam, ls), 0.0);
       al += pr * pr - l * l;
     }
     al = 0.5 / mu * al;
@@ -670,11 +693,11 @@ struct NewAlOps {
 #pragma unroll
       for (int j = 0; j < M; ++j) hu[i][j] = 0.0;
     for (int i = 0; i < a.C; ++i) {
-      double lp = fmin(lam[i * ls] - mu * cval(a, tab, x, u, i), 0.0);
+      double lp = fmin(lam[i * ls] - mu * cval(a, tab, x, u, i, lam, ls), 0.0);
       double on = (lp >= 0.0) ? 0.0 : 1.0;
       double cx[N], pa[N], pb[M];
 #pragma unroll
-      for (int j = 0; j < N; ++j) cx[j] = A[i * N + j];
+      for (int j = 0; j < N; ++j) cx[j] = a_ij(a, A, lam, ls, i, j);
       if (QUAD && ((a.quad_rows >> i) & 1ull)) {
         // c_x row: A_i + 2 Qc_i x ; constraint Hessian 2 Qc_i weighted by the projected multiplier
         // (quadratic_constraints.h:47-55, 86-88; constraints.h:797-802, 1341-1345)
@@ -726,11 +749,11 @@ struct NewAlOps {
                                      const double* lam, size_t ls, double mu) {
     double v = 0.0;
     for (int i = 0; i < a.C; ++i) {
-      double c = cval(a, tab, x, u, i);
+      double c = cval(a, tab, x, u, i, lam, ls);
       double dc = fabs(c - fmin(c, 0.0));
       v = (dc > v) ? dc : v;
     }
-    (void)lam; (void)ls; (void)mu;
+    (void)mu;
     return v;
   }
   __device__ static double combine_violation(double acc, double node) { return (node > acc) ? node : acc; }
@@ -738,15 +761,19 @@ struct NewAlOps {
   __device__ static void update_lambda(const KArgs& a, ctab tab, const double* x, const double* u,
                                        double* lam, size_t ls, double mu) {
     for (int i = 0; i < a.C; ++i) {
-      double c = cval(a, tab, x, u, i);
+      double c = cval(a, tab, x, u, i, lam, ls);
       lam[i * ls] = fmin(lam[i * ls] - mu * c, 0.0);
     }
   }
 };
 template <int MODEL>
-struct NodeOps<MODEL, ALILQR_MODE_NEW_AL> : NewAlOps<MODEL, false> {};
+struct NodeOps<MODEL, ALILQR_MODE_NEW_AL> : NewAlOps<MODEL, false, false> {};
 template <int MODEL>
-struct NodeOps<MODEL, kModeNewAlQuad> : NewAlOps<MODEL, true> {};
+struct NodeOps<MODEL, kModeNewAlQuad> : NewAlOps<MODEL, true, false> {};
+template <int MODEL>
+struct NodeOps<MODEL, kModeNewAlRect> : NewAlOps<MODEL, false, true> {};
+template <int MODEL>
+struct NodeOps<MODEL, kModeNewAlQuadRect> : NewAlOps<MODEL, true, true> {};
 
 
 // ---------------------------------------------------------------------------
@@ -773,9 +800,14 @@ struct NodeRec {
 };
 
 // doubles of one group's block (host and device must agree)
+// doubles of one step record: x | u | K | k | goal | lambda[C] (| overlay: sign[C] | C'[C] | row index)
+template <class MD, int MODE>
+__host__ __device__ constexpr int record_doubles(int C) {
+  return (RecLayout<MD>::rl + C + (is_rect(MODE) ? 2 * C + 1 : 0) + 1) & ~1;
+}
 template <class MD, int MODE>
 __host__ __device__ inline size_t block_doubles(int H, int C) {
-  const size_t RS = (size_t)((RecLayout<MD>::rl + C + 1) & ~1);
+  const size_t RS = (size_t)record_doubles<MD, MODE>(C);
   return (size_t)(H + 1) * (RS + NodeRec<MD, MODE>::E);
 }
 
@@ -810,7 +842,8 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   constexpr int N = MD::N, M = MD::M;
   constexpr bool LEGACY = (MODE == ALILQR_MODE_LEGACY);
   constexpr bool NEWAL = is_new_al(MODE);
-  constexpr bool QUAD = (MODE == kModeNewAlQuad);
+  constexpr bool QUAD = is_quad(MODE);
+  constexpr bool RECT = is_rect(MODE);
   constexpr bool PM = (G > 1);                         // block layout: problem-major (contiguous) or element-major
   constexpr int CL = LEGACY ? 2 * (N + M) : 1;         // multipliers held in registers (LEGACY only)
   constexpr int SS = TrjSlots<MODE>::SS;               // trajectory slots kept per problem and parity
@@ -825,7 +858,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   const size_t NG = (size_t)a.NG, LT = NG * G;
   const int XS = (H + 1) * N, US = H * M, T = XS + US;
   const ModelConst mc = a.mc;
-  const int RS = (RL::rl + C + 1) & ~1;
+  const int RS = record_doubles<MD, MODE>(C);
   const size_t ES = PM ? (size_t)1 : NG;               // element stride inside the block
   double* const blk = a.blk + (PM ? gid * block_doubles<MD, MODE>(H, C) : gid);
   double* const linb = blk + (size_t)(H + 1) * RS * ES;
@@ -940,6 +973,10 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
 #pragma unroll
           for (int i = 0; i < N; ++i) r[(size_t)(RL::rg + i) * ES] = goals[(size_t)t * N + i];
           for (int i = 0; i < C; ++i) r[(size_t)(RL::rl + i) * ES] = 0.0;
+          if (RECT) {
+            for (int i = 0; i < 2 * C; ++i) r[(size_t)(RL::rl + C + i) * ES] = 0.0;
+            r[(size_t)(RL::rl + 3 * C) * ES] = (double)a.first_row;
+          }
         }
         // ---- linearised-LQR initial guess (ilqr.py:11-50): every lane of the group
         //      carries the same recursion; lane 0 stores.
@@ -1072,10 +1109,60 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
 
     if (p >= 0) {
       // ================= outer-iteration start: J under the current multipliers =================
-      if (outer_start) {
+      bool tables_changed = false;
+      if (RECT) {
+        // ---- row activation (new_al_ilqr.h:525-625): nodes in parallel; a node inside a rectangle gets the
+        //      rectangle's y-bound written into the next row of its own table
+        bool mine = false;
+        for (int t = gl; t <= H; t += G) {
+          double* r = rec(t);
+          const double px = *trj_at(cur_par, t * N + 0, cur_slot), py = *trj_at(cur_par, t * N + 1, cur_slot);
+          ctab Cv = tabC(t) + C * (N + M);
+          for (int side = 0; side < 2; ++side) {
+            ctab obs = as_ctab(side == 0 ? a.left_obs : a.right_obs);
+            const int cnt = side == 0 ? a.n_left : a.n_right;
+            for (int k = 0; k < cnt; ++k) {
+              ctab vx = obs + (size_t)k * 8, vy = vx + 4;
+              bool inside = true;
+              double ext = vy[0];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int e2 = (e + 1) & 3;
+                const double ex = vx[e2] - vx[e], ey = vy[e2] - vy[e];
+                const double qx = px - vx[e], qy = py - vy[e];
+                const double cr = qx * ey - qy * ex;
+                if (!(cr < 0)) inside = false;
+                if (side == 0) { if (vy[e] > ext) ext = vy[e]; } else { if (vy[e] < ext) ext = vy[e]; }
+              }
+              if (!inside) continue;
+              const double sgn = (side == 0) ? -1.0 : 1.0, cnew = (side == 0) ? ext : -ext;
+              bool exist = false;
+              for (int i = 0; i < C; ++i) {
+                const double ci = (r[(size_t)(RL::rl + C + i) * ES] != 0.0) ? r[(size_t)(RL::rl + 2 * C + i) * ES] : Cv[i];
+                exist |= (ci == cnew);
+              }
+              if (exist) continue;
+              int idx = (int)r[(size_t)(RL::rl + 3 * C) * ES];
+              if (!QUAD) {
+                if (idx + 1 >= C) continue;          // the reference would write past its fixed-size table here
+                idx += 1;
+                r[(size_t)(RL::rl + 3 * C) * ES] = (double)idx;
+              }
+              if (idx < 0 || idx >= C) continue;
+              r[(size_t)(RL::rl + C + idx) * ES] = sgn;
+              r[(size_t)(RL::rl + 2 * C + idx) * ES] = cnew;
+              mine = true;
+            }
+          }
+        }
+        tables_changed = gfirst<G>(mine, lane) >= 0;
+        __threadfence_block();
+      }
+      if (outer_start || tables_changed) {
+        // J of the current trajectory under the current multipliers and tables (what CalcDerivatives leaves in cost_list_)
         old_cost = total_cost();
+        if (outer_start) inner = 0;
         outer_start = false;
-        inner = 0;
       }
       const int np_ = 1 - cur_par;              // parity the candidates are written to
 

@@ -222,3 +222,47 @@ def new_al_lat_circle(B, H=30, seed=10, circle=(30.0, 11.0, 6.0), x0=None):
         x0[:, 2] += 1.0      # the script starts with a heading of 1 rad
     return desc, np.ascontiguousarray(x0, dtype=np.float64), s_curve_goals(10.0, 0.1, H, False), Q, R, \
         capi.pack_quadratic(Qc, A, Bm, C)
+
+
+# rectangles of cilqr/test_rectangle_obs_pybind.py:74-80 (2 x 4 vertex matrices, counter-clockwise)
+DEMO_LEFT_OBS = [np.array([[32.0, 32, 28, 28], [13, 15, 15, 13]])]
+DEMO_RIGHT_OBS = [np.array([[18.0, 18, 14, 14], [3, 7, 7, 3]])]
+
+
+def new_al_lat_rect(B, H=50, seed=12, x0=None, u_bound=0.6):
+    """NewALILQR<4,1>(nodes, x0, left_obs, right_obs) + NewLatBicycleNode + LinearConstraints<4,1,6> whose rows 2..5
+    are the pool the rectangle activation fills (cilqr/test_rectangle_obs_pybind.py:45-95: first row index 1,
+    steering-rate bound 0.6, optimize(50, 100, 1e-4)).  Returns the problem and the keyword arguments
+    (left_obs, right_obs, first_row) the solve takes."""
+    A = np.zeros((6, 4)); Bm = np.zeros((6, 1)); C = np.zeros(6)
+    Bm[0, 0], Bm[1, 0] = 1.0, -1.0
+    C[0] = C[1] = -u_bound
+    desc = capi.make_problem("lat_k", "new_al", H, B, L=3.0, dt=0.1, v=10.0, k=0.001, c=6)
+    desc.prm.max_outer, desc.prm.max_inner = 50, 100
+    desc.prm.viol_stop, desc.prm.viol_lambda = 1e-4, 5e-4
+    Q = np.diag([1e-1, 1e-1, 1.0, 1e-9]) * 1e3
+    R = np.eye(1) * 1e2
+    if x0 is None:
+        x0 = lat_start_states(B, seed)
+    prob = (desc, np.ascontiguousarray(x0, dtype=np.float64), s_curve_goals(10.0, 0.1, H, False), Q, R,
+            capi.pack_linear(A, Bm, C))
+    return prob, dict(left_obs=DEMO_LEFT_OBS, right_obs=DEMO_RIGHT_OBS, first_row=1)
+
+
+def kin_rect(B, H=50, seed=1):
+    """Benchmark configuration 3: kinematic 6/2 model (k = 0), linear table of 8 rows (four control-bound rows +
+    a pool of four rows), the two demo rectangles activating y-bounds node by node, C++-generation solver,
+    weights of al_ilqr_cpp/test_new_al_ilqr.cc:127-137, start states (0, U(-1,1), U(-0.1,0.1), 0, 10+U(-1,1), 0)."""
+    c = 8
+    A = np.zeros((c, 6)); Bm = np.zeros((c, 2)); C = np.zeros(c)
+    Bm[0, 0], C[0] = 1.0, -0.2
+    Bm[1, 0], C[1] = -1.0, -0.2
+    Bm[2, 1], C[2] = 1.0, -1.0
+    Bm[3, 1], C[3] = -1.0, -1.0
+    desc = capi.make_problem("new_bicycle", "new_al", H, B, L=3.0, dt=0.1, v=10.0, k=0.0, c=c)
+    desc.prm.max_outer, desc.prm.max_inner = 50, 100
+    desc.prm.viol_stop, desc.prm.viol_lambda = 1e-3, 5e-3
+    Q = np.diag([1e-1, 1e-1, 1.0, 1e-9, 1e-6, 1e-6]) * 1e3
+    R = np.eye(2) * 1e2
+    prob = (desc, full_start_states(B, seed), s_curve_goals(10.0, 0.1, H, True), Q, R, capi.pack_linear(A, Bm, C))
+    return prob, dict(left_obs=DEMO_LEFT_OBS, right_obs=DEMO_RIGHT_OBS, first_row=3)

@@ -40,7 +40,7 @@ class _Constraints:
     def __init__(self):
         self._lambda = np.zeros(self.C)
         self._mu = 1.0
-        self._index = self.C - 1
+        self._index = 0          # current_constraints_index_ (constraints.h:1191)
 
     # `lambda` is a Python keyword: reachable as getattr(obj, "lambda") like on the pybind object, and as lambda_
     @property
@@ -278,8 +278,9 @@ class _NewALILQR:
     N = M = 0
 
     def __init__(self, ilqr_nodes, init_state, left_obs=None, right_obs=None):
-        if left_obs or right_obs:
-            raise NotImplementedError("rectangle-obstacle row activation (new_al_ilqr.h:525-625) is not on the GPU path")
+        self.left_obs = list(left_obs) if left_obs is not None else []
+        self.right_obs = list(right_obs) if right_obs is not None else []
+        capi.pack_rectangles(self.left_obs), capi.pack_rectangles(self.right_obs)      # shape check (TypeError)
         nodes = list(ilqr_nodes)
         if len(nodes) < 2:
             raise ValueError("a trajectory needs at least two nodes")
@@ -318,7 +319,12 @@ class _NewALILQR:
         if x0.ndim != 2 or x0.shape[1] != self.N:
             raise TypeError("x0 must be [B, n]")
         desc, goals, Q, R, T = self._describe(x0.shape[0], max_outer_iter, max_inner_iter, max_violation)
-        return batch.solve_batch(desc, x0, goals, Q, R, T, device=device)
+        # every node starts from the row index its constraint object was given (set_current_constraints_index)
+        first_row = self.ilqr_nodes[0].constraints_obj.get_current_constraints_index()
+        if any(nd.constraints_obj.get_current_constraints_index() != first_row for nd in self.ilqr_nodes):
+            raise ValueError("the constraint row index must be the same on every node of a trajectory")
+        return batch.solve_batch(desc, x0, goals, Q, R, T, device=device, left_obs=self.left_obs,
+                                 right_obs=self.right_obs, first_row=first_row)
 
     def optimize(self, max_outer_iter, max_inner_iter, max_violation):
         out = {k: v.cpu().numpy() for k, v in

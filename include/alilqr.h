@@ -126,7 +126,7 @@ int32_t alilqr_device_count(void);
  * (cilqr/ilqr.py:151-174, cilqr/fast_ilqr.py:136-159, new_al_ilqr.h:1177-1211). */
 int32_t alilqr_default_params(int32_t mode, alilqr_params* out);
 
-/* Bytes of device scratch alilqr_solve_batch will hold for this descriptor. */
+/* Upper bound of the bytes of device scratch a solve of this descriptor will hold. */
 int64_t alilqr_workspace_bytes(const alilqr_problem* p);
 
 /*
@@ -184,6 +184,44 @@ int32_t alilqr_solve_batch_multistart(const alilqr_problem* p,
                                       double* cost, double* viol,
                                       double* lam, double* mu,
                                       int32_t* status, void* stream);
+
+/*
+ * Optional inputs of alilqr_solve_batch_ex (a host struct; the pointers in it are device pointers).
+ *
+ * Rectangle obstacles (NEW_AL only) reproduce the row activation of NewALILQR::UpdateConstraints
+ * (al_ilqr_cpp/new_al_ilqr.h:525-625, constructor :134-208): at the top of every inner iteration, for every node
+ * whose (x, y) lies strictly inside a left rectangle the row  -y + y_max <= 0  is written into the node's own copy
+ * of the constraint table, for a right rectangle the row  y - y_min <= 0  (y_max / y_min = extreme y of the four
+ * vertices).  The write follows the reference's table classes: skipped when any C entry of the node's table
+ * already equals the new C; linear / box tables advance the node's row index and write there
+ * (linear_constraints.h:360-373, box_constraints.h:80-92); quadratic tables overwrite A and C of the row at
+ * the index without advancing it (quadratic_constraints.h:57-64); the B (and Qc) part of the row is left as it is.
+ * One deviation: where the reference would advance the index past the last row (undefined behaviour on its
+ * fixed-size matrices) the row is dropped.
+ * Rectangles are [n][2][4]: the x coordinates of the four vertices, then their y coordinates, vertices in
+ * counter-clockwise order (the inside test is "all four edge cross products < 0"), shared by the whole batch.
+ */
+typedef struct alilqr_extras {
+  const double* u_offset;    /* [B][H][m] or NULL: see alilqr_solve_batch_multistart */
+  const double* left_obs;    /* [n_left][2][4] or NULL */
+  const double* right_obs;   /* [n_right][2][4] or NULL */
+  int32_t n_left, n_right;   /* each 0..16 */
+  int32_t first_row;         /* initial row index of every node's table: set_current_constraints_index()
+                                (constraints.h:189-196), 0 if never called */
+  int32_t reserved;          /* 0 */
+} alilqr_extras;
+
+/* alilqr_solve_batch with the optional inputs above (ex may be NULL). */
+int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
+                              const double* x0, const double* goals,
+                              const double* Q, const double* R, const double* cons,
+                              const alilqr_extras* ex,
+                              double* x_out, double* u_out,
+                              double* node_x, double* node_u,
+                              double* x_init, double* u_init,
+                              double* cost, double* viol,
+                              double* lam, double* mu,
+                              int32_t* status, void* stream);
 
 /*
  * Parallel-in-time linearisation / quadratisation of N = B*(H+1) independent

@@ -498,6 +498,7 @@ static double compute_total_cost(py_solver* s) {           /* ilqr.py:52-56 */
 }
 
 _Thread_local const double* or_u_offset = NULL;
+_Thread_local const alilqr_extras* or_extras = NULL;
 
 /* ilqr.py:11-50 / fast_ilqr.py:10-49 */
 static void linearized_initial_guess(py_solver* s, double* x, double* u) {
@@ -805,9 +806,9 @@ int32_t oracle_max_threads(void) {
 #endif
 }
 
-int32_t oracle_solve_batch_multistart(const alilqr_problem* p,
+int32_t oracle_solve_batch_ex(const alilqr_problem* p,
                            const double* x0, const double* goals,
-                           const double* Q, const double* R, const double* cons, const double* u_offset,
+                           const double* Q, const double* R, const double* cons, const alilqr_extras* ex,
                            double* x_out, double* u_out, double* node_x, double* node_u,
                            double* x_init, double* u_init, double* cost, double* viol,
                            double* lam, double* mu, int32_t* status, int32_t threads) {
@@ -821,7 +822,8 @@ int32_t oracle_solve_batch_multistart(const alilqr_problem* p,
 #endif
   for (int b = 0; b < B; ++b) {
     const double* g = goals + ((p->goal_batch > 1) ? (size_t)b * xs : 0);
-    or_u_offset = u_offset ? u_offset + (size_t)b * us : NULL;
+    or_u_offset = (ex && ex->u_offset) ? ex->u_offset + (size_t)b * us : NULL;
+    or_extras = ex;
     int r = oracle_solve(p, x0 + (size_t)b * n, g, Q, R, cons,
                          x_out ? x_out + b * xs : NULL, u_out ? u_out + b * us : NULL,
                          node_x ? node_x + b * xs : NULL, node_u ? node_u + b * us : NULL,
@@ -830,10 +832,24 @@ int32_t oracle_solve_batch_multistart(const alilqr_problem* p,
                          lam ? lam + b * ls : NULL, mu ? mu + b : NULL,
                          status ? status + (size_t)b * ALILQR_STATUS_WORDS : NULL, NULL);
     or_u_offset = NULL;
+    or_extras = NULL;
     if (r != 0) rc = r;
   }
   (void)threads;
   return rc;
+}
+
+int32_t oracle_solve_batch_multistart(const alilqr_problem* p,
+                           const double* x0, const double* goals,
+                           const double* Q, const double* R, const double* cons, const double* u_offset,
+                           double* x_out, double* u_out, double* node_x, double* node_u,
+                           double* x_init, double* u_init, double* cost, double* viol,
+                           double* lam, double* mu, int32_t* status, int32_t threads) {
+  alilqr_extras ex;
+  memset(&ex, 0, sizeof(ex));
+  ex.u_offset = u_offset;
+  return oracle_solve_batch_ex(p, x0, goals, Q, R, cons, &ex, x_out, u_out, node_x, node_u, x_init, u_init,
+                               cost, viol, lam, mu, status, threads);
 }
 
 int32_t oracle_solve_batch(const alilqr_problem* p,

@@ -43,6 +43,14 @@ int32_t oracle_solve_batch(const alilqr_problem* p,
                            double* x_init, double* u_init, double* cost, double* viol,
                            double* lam, double* mu, int32_t* status, int32_t threads);
 
+/* Same argument list as alilqr_solve_batch_ex with host pointers (also those inside *ex). */
+int32_t oracle_solve_batch_ex(const alilqr_problem* p,
+                              const double* x0, const double* goals,
+                              const double* Q, const double* R, const double* cons, const alilqr_extras* ex,
+                              double* x_out, double* u_out, double* node_x, double* node_u,
+                              double* x_init, double* u_init, double* cost, double* viol,
+                              double* lam, double* mu, int32_t* status, int32_t threads);
+
 /* Same argument list as alilqr_solve_batch_multistart with host pointers. */
 int32_t oracle_solve_batch_multistart(const alilqr_problem* p,
                                       const double* x0, const double* goals,

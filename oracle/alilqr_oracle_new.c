@@ -10,8 +10,7 @@
  * by review against the cited lines and by the node / constraint formulas it
  * shares with the Python generations (tests compare those).
  *
- * Not restated (the reference paths marked "next"): rectangle-obstacle
- * activation (UpdateConstraints), equality constraints.
+ * Not restated (the reference path marked "next"): equality constraints.
  */
 #define _GNU_SOURCE   /* M_PI under -std=c11 */
 #include "alilqr_oracle.h"
@@ -27,6 +26,9 @@ typedef struct nw_node {
   int model, n, m, c;
   double L, dt, v, k;
   const double *Q, *R, *A, *B, *C;
+  double Aown[OR_NC * OR_NX], Cown[OR_NC];   /* the node's own copy of A and C (constraints are copied into the node,
+                                                new_bicycle_node.h:169-170); A and C point here */
+  int cur_index;                       /* current_constraints_index_ (constraints.h:1191) */
   const double* Qc;                    /* quadratic table: c matrices n x n, or NULL (quadratic_constraints.h:94) */
   double goal[OR_NX];
   double lam[OR_NC], mu;
@@ -349,8 +351,11 @@ static void nw_node_init(nw_node* nd, const alilqr_problem* p, int t,
   nd->R = R + (size_t)tt * m * m;
   const int quad = (p->cons_kind == ALILQR_CONS_QUADRATIC);
   const double* b = cons + (size_t)tt * (c * n + c * m + c + (quad ? c * n * n : 0));
-  nd->A = b; nd->B = b + c * n; nd->C = b + c * n + c * m;
+  memcpy(nd->Aown, b, sizeof(double) * c * n);
+  memcpy(nd->Cown, b + c * n + c * m, sizeof(double) * c);
+  nd->A = nd->Aown; nd->B = b + c * n; nd->C = nd->Cown;
   nd->Qc = quad ? b + c * n + c * m + c : NULL;
+  nd->cur_index = or_extras ? or_extras->first_row : 0;
   memcpy(nd->goal, goals + (size_t)t * n, sizeof(double) * n);
   nd->mu = 1.0;
 }
@@ -555,6 +560,53 @@ static void nw_parallel_search(nw_solver* s, double alpha, double* best_alpha, d
   *best_alpha = av[best];
 }
 
+/* LinearConstraints / BoxConstraints / QuadraticConstraints::UpdateConstraints
+ * (linear_constraints.h:360-373, box_constraints.h:80-92, quadratic_constraints.h:57-64) */
+static void nw_node_update_constraints(nw_node* nd, const double* A_row, double C_row) {
+  for (int i = 0; i < nd->c; ++i)
+    if (nd->Cown[i] == C_row) return;
+  if (!nd->Qc) {
+    if (nd->cur_index + 1 >= nd->c) return;   /* the reference would write past its fixed-size table here */
+    nd->cur_index += 1;
+  }
+  if (nd->cur_index < 0 || nd->cur_index >= nd->c) return;
+  memcpy(nd->Aown + (size_t)nd->cur_index * nd->n, A_row, sizeof(double) * nd->n);
+  nd->Cown[nd->cur_index] = C_row;
+}
+
+/* new_al_ilqr.h:525-625 with the edge vectors of the constructor :134-208 */
+static void nw_update_constraints(nw_solver* s) {
+  const alilqr_extras* ex = or_extras;
+  if (!ex) return;
+  int n = s->n;
+  for (int side = 0; side < 2; ++side) {
+    const double* obs = side == 0 ? ex->left_obs : ex->right_obs;
+    int cnt = side == 0 ? ex->n_left : ex->n_right;
+    if (!obs || cnt <= 0) continue;
+    for (int t = 0; t <= s->H; ++t) {
+      double px = s->x[(size_t)t * n + 0], py = s->x[(size_t)t * n + 1];
+      for (int k = 0; k < cnt; ++k) {
+        const double* vx = obs + (size_t)k * 8;       /* x of the four vertices */
+        const double* vy = vx + 4;                    /* y of the four vertices */
+        int inside = 1;
+        double ext = vy[0];
+        for (int e = 0; e < 4; ++e) {
+          int e2 = (e + 1) & 3;
+          double ex_ = vx[e2] - vx[e], ey_ = vy[e2] - vy[e];        /* edge vector */
+          double qx = px - vx[e], qy = py - vy[e];
+          double cr = qx * ey_ - qy * ex_;                            /* MultiVectorCross :215-222 */
+          if (!(cr < 0)) inside = 0;
+          if (side == 0) { if (vy[e] > ext) ext = vy[e]; } else { if (vy[e] < ext) ext = vy[e]; }
+        }
+        if (!inside) continue;
+        double A_row[OR_NX] = {0};
+        A_row[1] = (side == 0) ? -1.0 : 1.0;
+        nw_node_update_constraints(&s->nodes[t], A_row, (side == 0) ? ext : -ext);
+      }
+    }
+  }
+}
+
 /* :1013-1077 */
 static void nw_forward(nw_solver* s) {
   int H = s->H, n = s->n, m = s->m;
@@ -620,6 +672,7 @@ int32_t or_new_solve(const alilqr_problem* p,
   if (trace) trace->length = 0;
   for (int outer = 0; outer < p->prm.max_outer; ++outer) {
     for (int iter = 0; iter < p->prm.max_inner; ++iter) {          /* ILQRProcess :1090-1122 */
+      nw_update_constraints(&s);
       nw_calc_derivatives(&s);
       double old_cost = sum_cost(&s);
       nw_backward(&s);

@@ -35,6 +35,9 @@ void or_py_jacobian(const or_node* nd, const double* s, const double* u, double*
 /* multi-start: offsets [H][m] added to the initial-guess controls of the solve running on this thread, or NULL */
 extern _Thread_local const double* or_u_offset;
 
+/* optional inputs (rectangle obstacles, first row index) of the solve running on this thread, or NULL */
+extern _Thread_local const alilqr_extras* or_extras;
+
 /* NEW_AL generation (alilqr_oracle_new.c) */
 int32_t or_new_solve(const alilqr_problem* p,
                      const double* x0, const double* goals,

@@ -25,6 +25,7 @@ def lib():
         _LIB.oracle_solve.restype = C.c_int32
         _LIB.oracle_solve_batch.restype = C.c_int32
         _LIB.oracle_solve_batch_multistart.restype = C.c_int32
+        _LIB.oracle_solve_batch_ex.restype = C.c_int32
         _LIB.oracle_linearize_batch.restype = C.c_int32
         _LIB.oracle_max_threads.restype = C.c_int32
     return _LIB
@@ -34,17 +35,21 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def solve_batch(desc, x0, goals, Q, R, cons, threads=0, extras=True, u_offset=None):
+def solve_batch(desc, x0, goals, Q, R, cons, threads=0, extras=True, u_offset=None, left_obs=None, right_obs=None,
+                first_row=0):
     """Run the oracle on a batch; arrays are host numpy float64, C-contiguous."""
     B, H, n, m, c = desc.batch, desc.horizon, desc.n, desc.m, desc.c
     out = capi.alloc_outputs_numpy(B, H, n, m, c, extras)
     args = [np.ascontiguousarray(a, dtype=np.float64) for a in (x0, goals, Q, R, cons)]
     uo = None if u_offset is None else np.ascontiguousarray(u_offset, dtype=np.float64)
     assert uo is None or uo.size == B * H * m
-    rc = lib().oracle_solve_batch_multistart(C.byref(desc), *[_p(a) for a in args], _p(uo),
-                                  _p(out["x"]), _p(out["u"]), _p(out.get("node_x")), _p(out.get("node_u")),
-                                  _p(out.get("x_init")), _p(out.get("u_init")), _p(out["cost"]), _p(out.get("viol")),
-                                  _p(out.get("lam")), _p(out.get("mu")), _p(out.get("status")), C.c_int32(threads))
+    lo, ro = capi.pack_rectangles(left_obs), capi.pack_rectangles(right_obs)
+    ex = capi.Extras(None if uo is None else uo.ctypes.data, lo.ctypes.data if len(lo) else None,
+                     ro.ctypes.data if len(ro) else None, len(lo), len(ro), int(first_row), 0)
+    rc = lib().oracle_solve_batch_ex(C.byref(desc), *[_p(a) for a in args], C.byref(ex),
+                                     _p(out["x"]), _p(out["u"]), _p(out.get("node_x")), _p(out.get("node_u")),
+                                     _p(out.get("x_init")), _p(out.get("u_init")), _p(out["cost"]), _p(out.get("viol")),
+                                     _p(out.get("lam")), _p(out.get("mu")), _p(out.get("status")), C.c_int32(threads))
     if rc != 0:
         raise RuntimeError(f"oracle_solve_batch failed: {rc}")
     return out

@@ -101,3 +101,32 @@ def test_multi_start_matches_oracle_and_picks_the_same_winner(mode):
             second = np.partition(ref["cost"][s * starts:(s + 1) * starts], 1)[1]
             if second - rc[s] > 1e-5 * max(1.0, abs(rc[s])):
                 assert bi[s] == ri[s]
+
+
+@pytest.mark.parametrize("name", ["lat_rect_demo", "kin_rect_config3"])
+@pytest.mark.parametrize("lanes", ["auto", "1", "8"])
+def test_rectangle_obstacle_activation_matches_oracle(name, lanes, monkeypatch):
+    """Row activation by rectangle obstacles (new_al_ilqr.h:525-625): the reference's lateral demo and benchmark
+    configuration 3 (kinematic model + linear table + rectangles)."""
+    if lanes != "auto":
+        monkeypatch.setenv("ALILQR_LANES", lanes)
+    prob, kw = (problems.new_al_lat_rect(32) if name == "lat_rect_demo" else problems.kin_rect(32))
+    ref = ol.solve_batch(*prob, **kw)
+    o = to_np(batch.solve_batch(*prob, **kw))
+    desc, x0 = prob[0], prob[1]
+    bump = np.zeros_like(x0); bump[:, 1] = 1e-13
+    ref2 = ol.solve_batch(desc, x0 + bump, *prob[2:6], **kw)
+    ok = np.array([worst_err(ref2, ref, i) < 1e-8 for i in range(desc.batch)])
+    assert ok.mean() >= 0.7, ok.mean()
+    for i in np.nonzero(ok)[0]:
+        assert worst_err(o, ref, i) < TOL, (name, i, o["status"][i], ref["status"][i])
+    assert (o["status"][ok] == ref["status"][ok]).all(axis=1).mean() > 0.9
+    assert gu.rel_err(o["lam"][ok], ref["lam"][ok]) < 1e-5
+    # the obstacles did something: the solve without them differs
+    free = to_np(batch.solve_batch(*prob))
+    assert np.abs(free["x"] - o["x"]).max() > 1.0
+    # rectangles nobody enters: bit-identical to the plain kernel variant
+    far = [np.array([[1032.0, 1032, 1028, 1028], [13, 15, 15, 13]])]
+    same = to_np(batch.solve_batch(*prob, left_obs=far, first_row=kw["first_row"]))
+    for k in ("x", "u", "cost", "status"):
+        assert np.array_equal(same[k], free[k]), k

@@ -134,3 +134,26 @@ def test_pybind_shaped_quadratic_constraints_flow():
     # (the goal curve runs through the centre of this circle, where the constraint gradient vanishes: the
     #  algorithm, in the oracle as here, ends at the outer-iteration cap without leaving it — not asserted)
     assert s.last_status["outer"] == ref["status"][0, 1]
+
+
+def test_pybind_shaped_rectangle_obstacle_flow():
+    """cilqr/test_rectangle_obs_pybind.py:45-95 through the ilqr_pybind-shaped classes."""
+    import oracle_lib as ol
+    from ilqr_amd import problems, pybind_api as ip
+    v, dt, L, k, H = 10.0, 0.1, 3.0, 0.001, 50
+    goals = problems.s_curve_goals(v, dt, H, False)
+    Q = np.diag([1e-1, 1e-1, 1e-0, 1e-9]) * 1e3
+    R = np.array([[1.0]]) * 1e2
+    A = np.zeros((6, 4)); B = np.zeros((6, 1)); C = np.zeros((6, 1))
+    B[0, 0], B[1, 0], C[0, 0], C[1, 0] = 1, -1, -0.6, -0.6
+    lin = ip.LinearConstraints4_1_6(A, B, C)
+    lin.set_current_constraints_index(1)
+    nodes = [ip.NewLatBicycleNodeLinearConstraints4_1_6(L, dt, k, v, goals[i], Q, R, lin) for i in range(H + 1)]
+    s = ip.NewALILQR4_1(nodes, np.zeros(4), problems.DEMO_LEFT_OBS, problems.DEMO_RIGHT_OBS)
+    s.optimize(50, 100, 1e-4)
+    x = s.get_x_list()
+    prob, kw = problems.new_al_lat_rect(1, x0=np.zeros((1, 4)))
+    ref = ol.solve_batch(*prob, **kw)
+    assert gu.rel_err(x.T, ref["x"][0]) < 1e-6 and s.last_status["inner"] == ref["status"][0, 0]
+    inside = (x[0] > 28) & (x[0] < 32) & (x[1] > 13) & (x[1] < 15)
+    assert not inside.any()

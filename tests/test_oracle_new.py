@@ -158,3 +158,38 @@ def test_reference_circle_demo_converges_and_clears_the_obstacle():
     dist = np.hypot(out["x"][0, :, 0] - 20.0, out["x"][0, :, 1] - 12.0)
     assert dist.min() > 4.0 - 1e-3          # the goal curve itself passes 1.7 m from the centre
     assert np.hypot(goals[:, 0] - 20.0, goals[:, 1] - 12.0).min() < 2.0
+
+
+def test_rectangle_activation_follows_the_reference_rules():
+    """cilqr/test_rectangle_obs_pybind.py:45-95 (LinearConstraints4_1_6, row index 1, two rectangles): the solve
+    converges, no node ends strictly inside a rectangle, nodes that crossed the left rectangle carry the row
+    -y + 15 <= 0 and those that crossed the right one y - 3 <= 0, written from row 2 on (linear_constraints.h:360-373)."""
+    prob, kw = problems.new_al_lat_rect(1, x0=np.zeros((1, 4)))
+    out = ol.solve_batch(*prob, **kw)
+    free = ol.solve_batch(*prob)
+    assert out["status"][0, 2] == capi.FLAG_VIOL_OK and out["viol"][0] < 1e-4
+    x, g = out["x"][0], prob[2]
+    in_left = (x[:, 0] > 28) & (x[:, 0] < 32) & (x[:, 1] > 13) & (x[:, 1] < 15)
+    in_right = (x[:, 0] > 14) & (x[:, 0] < 18) & (x[:, 1] > 3) & (x[:, 1] < 7)
+    assert not in_left.any() and not in_right.any()
+    # the goal curve itself runs through both rectangles, and so does the unconstrained solve
+    xf = free["x"][0]
+    assert ((g[:, 0] > 28) & (g[:, 0] < 32) & (g[:, 1] > 13) & (g[:, 1] < 15)).any()
+    assert ((xf[:, 0] > 14) & (xf[:, 0] < 18) & (xf[:, 1] > 3) & (xf[:, 1] < 7)).any()
+    # bounds respected where they were activated: y >= 15 next to the left rectangle, y <= 3 next to the right one
+    near_left = (x[:, 0] > 28) & (x[:, 0] < 32)
+    near_right = (x[:, 0] > 14) & (x[:, 0] < 18)
+    assert np.all(x[near_left, 1] >= 15 - 1e-3) and np.all(x[near_right, 1] <= 3 + 1e-3)
+    # multipliers only ever appear on the two static rows and on pool rows 2, 3
+    used = np.abs(out["lam"][0]).max(axis=0) > 0
+    assert not used[4:].any()
+
+
+def test_rectangles_without_effect_change_nothing():
+    """Rectangles nobody enters leave the solve bit-identical to the plain one."""
+    prob, kw = problems.new_al_lat_rect(4)
+    far = [np.array([[132.0, 132, 128, 128], [13, 15, 15, 13]])]
+    a = ol.solve_batch(*prob, left_obs=far, right_obs=far, first_row=1)
+    b = ol.solve_batch(*prob)
+    for k in ("x", "u", "cost", "status"):
+        assert np.array_equal(a[k], b[k]), k

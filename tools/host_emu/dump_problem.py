@@ -13,11 +13,20 @@ def main():
             "lat_legacy": lambda: problems.lat_legacy(B), "fast_box": lambda: problems.fast_box(B),
             "dyn_legacy": lambda: problems.full_legacy("dyn", B, 60, 3),
             "circle6": lambda: problems.new_al_circle(B), "lat_circle": lambda: problems.new_al_lat_circle(B)}
-    desc, x0, goals, Q, R, cons = sets[name]()
+    kw = {}
+    if name in ("lat_rect", "kin_rect"):
+        (desc, x0, goals, Q, R, cons), kw = (problems.new_al_lat_rect if name == "lat_rect" else problems.kin_rect)(B)
+    else:
+        desc, x0, goals, Q, R, cons = sets[name]()
     with open(out, "wb") as f:
         f.write(bytes(desc))
         for a in (x0, goals, Q, R, cons):
             f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+        if kw:
+            from ilqr_amd import capi
+            lo, ro = capi.pack_rectangles(kw["left_obs"]), capi.pack_rectangles(kw["right_obs"])
+            f.write(np.array([len(lo), len(ro), kw["first_row"], 0], dtype=np.int32).tobytes())
+            f.write(lo.tobytes()); f.write(ro.tobytes())
 
 if __name__ == "__main__":
     main()
