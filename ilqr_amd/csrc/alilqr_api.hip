@@ -30,13 +30,18 @@ void set_err(const char* fmt, const char* a = "", const char* b = "") {
     }                                                                        \
   } while (0)
 
-// grow-only device scratch, one per device
+// Grow-only device scratch, one per (device, stream): solves enqueued on different streams of a device may
+// overlap on the GPU (the tail of one batch leaves most of the machine idle, the next batch fills it), so each
+// stream works in its own scratch.
 struct Workspace {
   void* ptr = nullptr;
   size_t bytes = 0;
+  hipStream_t stream = nullptr;
+  bool used = false;
 };
-constexpr int kMaxDev = 16;
-Workspace g_ws[kMaxDev];
+constexpr int kMaxDev = 16, kMaxStreams = 8;
+Workspace g_ws[kMaxDev][kMaxStreams];
+void* g_last_ws[kMaxDev] = {};   // scratch of the most recent solve on the device (profiling builds read it)
 std::mutex g_mu;
 
 struct Dims {
@@ -351,13 +356,20 @@ int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
   char* base = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    Workspace& w = g_ws[dev];
+    Workspace* slot = nullptr;
+    for (int i = 0; i < kMaxStreams && !slot; ++i)
+      if (g_ws[dev][i].used && g_ws[dev][i].stream == st) slot = &g_ws[dev][i];
+    for (int i = 0; i < kMaxStreams && !slot; ++i)
+      if (!g_ws[dev][i].used) { slot = &g_ws[dev][i]; slot->used = true; slot->stream = st; }
+    if (!slot) { set_err("more than 8 streams solve on this device; call alilqr_release() to start over"); return ALILQR_E_ARG; }
+    Workspace& w = *slot;
     if (w.bytes < pl.total) {
-      if (w.ptr) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(w.ptr)); w.ptr = nullptr; w.bytes = 0; }
+      if (w.ptr) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(w.ptr)); w.ptr = nullptr; w.bytes = 0; }
       hipError_t e = hipMalloc(&w.ptr, pl.total);
       if (e != hipSuccess) { set_err("hipMalloc(workspace): %s", hipGetErrorString(e)); w.ptr = nullptr; return ALILQR_E_NOMEM; }
       w.bytes = pl.total;
     }
+    g_last_ws[dev] = w.ptr;
     base = (char*)w.ptr;
   }
   HIP_TRY(hipMemsetAsync(base + pl.counter, 0, 256, st));
@@ -461,9 +473,9 @@ int32_t alilqr_linearize_batch(const alilqr_problem* p,
 /* profiling builds only: copy the 9 phase counters of the last solve on this device to the host */
 int32_t alilqr_prof_read(unsigned long long* out) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || !g_ws[dev].ptr) return ALILQR_E_HIP;
+  if (hipGetDevice(&dev) != hipSuccess || !g_last_ws[dev]) return ALILQR_E_HIP;
   if (hipDeviceSynchronize() != hipSuccess) return ALILQR_E_HIP;
-  if (hipMemcpy(out, (char*)g_ws[dev].ptr + 128, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return ALILQR_E_HIP;
+  if (hipMemcpy(out, (char*)g_last_ws[dev] + 128, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return ALILQR_E_HIP;
   return ALILQR_OK;
 }
 #endif
@@ -471,17 +483,18 @@ int32_t alilqr_prof_read(unsigned long long* out) {
 int32_t alilqr_release(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (int i = 0; i < kMaxDev; ++i) {
-    if (g_ws[i].ptr) {
-      int cur = 0;
-      if (hipGetDevice(&cur) == hipSuccess) {
-        (void)hipSetDevice(i);
-        (void)hipDeviceSynchronize();
-        (void)hipFree(g_ws[i].ptr);
-        (void)hipSetDevice(cur);
-      }
-      g_ws[i].ptr = nullptr;
-      g_ws[i].bytes = 0;
+    bool any = false;
+    for (int k = 0; k < kMaxStreams; ++k) any |= (g_ws[i][k].ptr != nullptr);
+    int cur = 0;
+    if (any && hipGetDevice(&cur) == hipSuccess) {
+      (void)hipSetDevice(i);
+      (void)hipDeviceSynchronize();
+      for (int k = 0; k < kMaxStreams; ++k)
+        if (g_ws[i][k].ptr) (void)hipFree(g_ws[i][k].ptr);
+      (void)hipSetDevice(cur);
     }
+    for (int k = 0; k < kMaxStreams; ++k) g_ws[i][k] = Workspace{};
+    g_last_ws[i] = nullptr;
   }
   return ALILQR_OK;
 }

@@ -153,6 +153,8 @@ int64_t alilqr_workspace_bytes(const alilqr_problem* p);
  *       status [B][ALILQR_STATUS_WORDS]   (may be NULL)
  *  stream      hipStream_t to enqueue on (NULL = default stream); the call
  *              returns after enqueueing, outputs are valid once the stream drains.
+ *              Every stream (up to 8 per device) gets its own scratch, so solves on different streams
+ *              may overlap on the GPU; solves on one stream run in order.
  * Returns ALILQR_OK or a negative alilqr_status; never throws.
  */
 int32_t alilqr_solve_batch(const alilqr_problem* p,

@@ -17,17 +17,23 @@ def main():
         "new_al box6 H50": problems.new_al_box(B),
         "new_al lat4 H50": problems.new_al_lat(B),
         "new_al kin+linear H50": problems.kin_linear(B),
+        "new_al circle6 H50": problems.new_al_circle(B),
+        "new_al kin+rect H50": problems.kin_rect(B),
     }
     only = sys.argv[1:]
     for name, prob in sets.items():
         if only and not any(o in name for o in only):
             continue
-        s = batch.BatchSolver(*prob)
-        s.run(); torch.cuda.synchronize()
+        kw = {}
+        if isinstance(prob[0], tuple):
+            prob, kw = prob
+        ins = [torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device="cuda:0") for a in prob[1:]]
+        run = lambda: batch.solve_batch(prob[0], *ins, extras=True, sync=False, **kw)
+        run(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(3):
-            o = s.run()
+            o = run()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
         st = o["status"].cpu().numpy()
