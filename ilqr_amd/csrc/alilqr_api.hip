@@ -368,11 +368,15 @@ int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
       hipError_t e = hipMalloc(&w.ptr, pl.total);
       if (e != hipSuccess) { set_err("hipMalloc(workspace): %s", hipGetErrorString(e)); w.ptr = nullptr; return ALILQR_E_NOMEM; }
       w.bytes = pl.total;
+      // counters start at zero; every solve leaves them at zero again (kernel epilogue)
+      HIP_TRY(hipMemsetAsync((char*)w.ptr + pl.counter, 0, 256, st));
     }
     g_last_ws[dev] = w.ptr;
     base = (char*)w.ptr;
   }
-  HIP_TRY(hipMemsetAsync(base + pl.counter, 0, 256, st));
+#ifdef ALILQR_PROF
+  HIP_TRY(hipMemsetAsync(base + pl.counter, 0, 256, st));   /* profiling builds keep their phase counters here too */
+#endif
 
   alilqr::KArgs ka{};
   ka.B = p->batch; ka.NG = pl.NG; ka.H = p->horizon; ka.C = p->c;

@@ -1644,6 +1644,18 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
     }
   }
   PROF_FLUSH(a)
+  // The last wave to drain puts the two counters back to zero for the next launch on this scratch, which
+  // saves a fill dispatch per solve (a dispatch that would queue behind the resident waves of other streams).
+  // A wave counts itself done only after it saw the problem counter run out, so nobody pulls after the reset.
+  if (lane == 63) {
+    __threadfence();
+    const unsigned done = atomicAdd(a.counter + 1, 1u);
+    if (done == gridDim.x - 1) {
+      __threadfence();
+      a.counter[0] = 0u;
+      a.counter[1] = 0u;
+    }
+  }
 }
 
 }  // namespace alilqr

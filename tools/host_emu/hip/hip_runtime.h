@@ -18,7 +18,7 @@
 
 struct emu_dim3 { unsigned x = 1, y = 1, z = 1; emu_dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 typedef emu_dim3 dim3;
-inline thread_local emu_dim3 threadIdx, blockIdx, blockDim;
+inline thread_local emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 // ---- lane groups as threads: the G lanes of a group run as G threads that meet at every cross-lane
 //      primitive; groups are independent and run one after the other.
@@ -62,6 +62,7 @@ inline bool __any(bool p) { return p; }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 // lanes of a wave run in lockstep on the GPU, so a fence orders one lane's stores before the next phase's
 // loads of the other lanes; threads need a rendezvous for the same effect
+inline void __threadfence() {}
 inline void __threadfence_block() { emu_group* g = emu_grp; if (g && g->G > 1) pthread_barrier_wait(&g->bar); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
@@ -95,7 +96,7 @@ inline int emu_group_width() { const char* e = std::getenv("ALILQR_LANES"); int 
         std::vector<std::thread> th_;                                               \
         for (int g_ = 0; g_ < G_; ++g_)                                             \
           th_.emplace_back([&, g_] {                                                \
-            blockDim = block_; blockIdx.x = b_; threadIdx.x = l0_ + g_;             \
+            blockDim = block_; gridDim = grid_; blockIdx.x = b_; threadIdx.x = l0_ + g_;             \
             emu_grp = &grp_; emu_gl = g_;                                           \
             kernel(__VA_ARGS__);                                                    \
           });                                                                       \
