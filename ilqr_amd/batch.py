@@ -141,3 +141,27 @@ def linearize_batch(desc, x, u, lam, mu, goals, Q, R, cons, device="cuda:0"):
         capi.check(rc, "alilqr_linearize_batch")
         torch.cuda.synchronize(dev)
     return out
+
+
+def node_aux_batch(desc, x, u, lam, mu, goals, Q, R, cons, device="cuda:0"):
+    """Constraint values, one multiplier update, the node's violation term and (NEW_AL) the parallel cost and
+    f_xx on B*(H+1) nodes in parallel."""
+    torch = _torch()
+    lib = capi.load_library()
+    dev = _require_gpu(device)
+    B, H, n, m, c = desc.batch, desc.horizon, desc.n, desc.m, desc.c
+    ins = [_dev_f64(a, dev) for a in (x, u, lam, mu, goals, Q, R, cons)]
+    f64 = dict(dtype=torch.float64, device=dev)
+    new_al = desc.mode == capi.MODES["new_al"]
+    out = dict(cval=torch.empty((B, H + 1, c), **f64), lam_new=torch.empty((B, H + 1, c), **f64),
+               viol=torch.empty((B, H + 1), **f64))
+    if new_al:
+        out.update(par_cost=torch.empty((B, H + 1), **f64), fxx=torch.empty((B, H + 1, 3, n, n), **f64))
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.alilqr_node_aux_batch(C.byref(desc), *[_ptr(t) for t in ins],
+                                       _ptr(out["cval"]), _ptr(out["lam_new"]), _ptr(out["viol"]),
+                                       _ptr(out.get("par_cost")), _ptr(out.get("fxx")), C.c_void_p(stream))
+        capi.check(rc, "alilqr_node_aux_batch")
+        torch.cuda.synchronize(dev)
+    return out

@@ -130,7 +130,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "lib
 
 EXPORTS = ("alilqr_abi_version", "alilqr_last_error", "alilqr_device_count", "alilqr_default_params",
            "alilqr_workspace_bytes", "alilqr_solve_batch", "alilqr_solve_batch_multistart", "alilqr_solve_batch_ex",
-           "alilqr_linearize_batch",
+           "alilqr_linearize_batch", "alilqr_node_aux_batch",
            "alilqr_release")
 
 
@@ -167,6 +167,8 @@ def load_library():
     lib.alilqr_solve_batch_ex.restype = C.c_int32
     lib.alilqr_solve_batch_ex.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 5 + [C.POINTER(Extras)] + [C.c_void_p] * 12
     lib.alilqr_linearize_batch.restype = C.c_int32
+    lib.alilqr_node_aux_batch.restype = C.c_int32
+    lib.alilqr_node_aux_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 14
     lib.alilqr_linearize_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17
     lib.alilqr_release.restype = C.c_int32
     if lib.alilqr_abi_version() != ABI_VERSION:

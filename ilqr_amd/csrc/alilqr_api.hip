@@ -187,6 +187,7 @@ struct LArgs {
   alilqr::ModelConst mc;
   const double *x, *u, *lam, *mu, *goals, *Q, *R, *cons;
   double *f, *fx, *fu, *l, *lx, *lu, *lxx, *luu;
+  double *cval, *lam_new, *viol, *pcost, *fxx;   // alilqr_node_aux_batch
 };
 
 template <int MODEL, int MODE>
@@ -241,6 +242,37 @@ __global__ __launch_bounds__(256) void linearize_kernel(LArgs a) {
   if (a.lu) for (int q = 0; q < M; ++q) a.lu[i * M + q] = rec[LL::oLu + q];
   if (a.lxx) for (int q = 0; q < N * N; ++q) a.lxx[i * N * N + q] = rec[LL::oLxx + q];
   if (a.luu) for (int q = 0; q < M * M; ++q) a.luu[i * M * M + q] = rec[LL::oLuu + q];
+  // ---- the remaining per-node calls (alilqr_node_aux_batch)
+  if (a.cval || a.lam_new) {
+    double ln[64];
+    for (int q = 0; q < a.C; ++q) ln[q] = lam[q];
+    if constexpr (MODE == ALILQR_MODE_LEGACY) {
+      if (a.cval) for (int q = 0; q < a.C; ++q) a.cval[i * a.C + q] = OPS::cval(tab, x, u, q);
+    } else if constexpr (is_new_al(MODE)) {
+      if (a.cval) for (int q = 0; q < a.C; ++q) a.cval[i * a.C + q] = OPS::cval(ka, tab, x, u, q, lam, 1);
+    } else {
+      if (a.cval) for (int q = 0; q < a.C; ++q) a.cval[i * a.C + q] = OPS::cval(ka, tab, x, u, q);
+    }
+    if (a.lam_new) {
+      OPS::update_lambda(ka, tab, x, u, ln, 1, mu);
+      for (int q = 0; q < a.C; ++q) a.lam_new[i * a.C + q] = ln[q];
+    }
+  }
+  if (a.viol) a.viol[i] = OPS::violation(ka, tab, x, u, lam, 1, mu);
+  if constexpr (is_new_al(MODE)) {
+    if (a.pcost) a.pcost[i] = OPS::par_cost(ka, Q, R, tab, x, u, g, lam, 1, mu);
+    if (a.fxx) {
+      double ff[8];
+      MD::fxx(a.mc, x, u, ff);
+      for (int k = 0; k < 3; ++k) {
+        double e[3] = {0.0, 0.0, 0.0};
+        e[k] = 1.0;
+        for (int r = 0; r < N; ++r)
+          for (int q = 0; q < N; ++q)
+            a.fxx[((i * 3 + k) * N + r) * N + q] = MD::fxx_nz(r, q) ? MD::fxx_term(ff, e, r, q) : 0.0;
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -426,17 +458,19 @@ int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
   return ALILQR_E_ARG;
 }
 
-int32_t alilqr_linearize_batch(const alilqr_problem* p,
-                               const double* x, const double* u,
-                               const double* lam, const double* mu,
-                               const double* goals, const double* Q, const double* R, const double* cons,
-                               double* f, double* fx, double* fu, double* l,
-                               double* lx, double* lu, double* lxx, double* luu,
-                               void* stream) {
+static int32_t node_eval(const alilqr_problem* p,
+                         const double* x, const double* u,
+                         const double* lam, const double* mu,
+                         const double* goals, const double* Q, const double* R, const double* cons,
+                         double* f, double* fx, double* fu, double* l,
+                         double* lx, double* lu, double* lxx, double* luu,
+                         double* cval, double* lam_new, double* viol, double* pcost, double* fxx,
+                         void* stream) {
   Dims d;
   int32_t rc = check_problem(p, &d);
   if (rc != ALILQR_OK) return rc;
   if (p->batch == 0) return ALILQR_OK;
+  if ((pcost || fxx) && p->mode != ALILQR_MODE_NEW_AL) { set_err("par_cost and fxx exist for NEW_AL only"); return ALILQR_E_ARG; }
   if (!x || !u || !lam || !mu || !goals || !Q || !R || !cons) { set_err("null input"); return ALILQR_E_ARG; }
   {
     int n = 0;
@@ -447,6 +481,7 @@ int32_t alilqr_linearize_batch(const alilqr_problem* p,
   a.quad = (p->cons_kind == ALILQR_CONS_QUADRATIC) ? 1 : 0;
   a.mc = {p->L, p->dt, p->v, p->k};
   a.x = x; a.u = u; a.lam = lam; a.mu = mu; a.goals = goals; a.Q = Q; a.R = R; a.cons = cons;
+  a.cval = cval; a.lam_new = lam_new; a.viol = viol; a.pcost = pcost; a.fxx = fxx;
   a.f = f; a.fx = fx; a.fu = fu; a.l = l; a.lx = lx; a.lu = lu; a.lxx = lxx; a.luu = luu;
   const size_t total = (size_t)p->batch * (p->horizon + 1);
   dim3 block(256), grid((unsigned)((total + 255) / 256));
@@ -471,6 +506,27 @@ int32_t alilqr_linearize_batch(const alilqr_problem* p,
   }
   HIP_TRY(hipGetLastError());
   return ALILQR_OK;
+}
+
+int32_t alilqr_linearize_batch(const alilqr_problem* p,
+                               const double* x, const double* u,
+                               const double* lam, const double* mu,
+                               const double* goals, const double* Q, const double* R, const double* cons,
+                               double* f, double* fx, double* fu, double* l,
+                               double* lx, double* lu, double* lxx, double* luu,
+                               void* stream) {
+  return node_eval(p, x, u, lam, mu, goals, Q, R, cons, f, fx, fu, l, lx, lu, lxx, luu,
+                   nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int32_t alilqr_node_aux_batch(const alilqr_problem* p,
+                              const double* x, const double* u,
+                              const double* lam, const double* mu,
+                              const double* goals, const double* Q, const double* R, const double* cons,
+                              double* cval, double* lam_new, double* viol, double* par_cost, double* fxx,
+                              void* stream) {
+  return node_eval(p, x, u, lam, mu, goals, Q, R, cons, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                   cval, lam_new, viol, par_cost, fxx, stream);
 }
 
 #ifdef ALILQR_PROF

@@ -244,10 +244,35 @@ class _Node:
         o = self._eval(state, control)
         return o["lxx"], o["luu"]
 
-    def _later(self, *a, **k):
-        raise NotImplementedError("this per-node method is not exposed by the GPU library; the solver computes it in-kernel")
+    def _aux(self, state, control):
+        c = self.constraints_obj
+        desc = capi.make_problem(self.MODEL, "new_al", 1, 1, self.L, self.dt, v=self.v, k=self.k, c=c.C, cons_kind=c.KIND)
+        x = np.zeros((1, 2, self.N)); x[0, 0] = _vec(state, self.N, "state")
+        u = np.zeros((1, 2, self.M)); u[0, 0] = _vec(control, self.M, "control")
+        lam = np.zeros((1, 2, c.C)); lam[0, 0] = c.lambda_
+        out = batch.node_aux_batch(desc, x, u, lam, np.array([c.mu]), np.tile(self._goal, (2, 1)),
+                                   self.Q[None], self.R[None], c.table()[None])
+        return {k: v[0, 0].cpu().numpy() for k, v in out.items()}
 
-    parallel_cost = dynamics_hessian_fxx = update_lambda = max_constraints_violation = _later
+    def parallel_cost(self, state, control):
+        """One value per column of the (n x 5, m x 5) arguments, as NewILQRNode::parallel_cost returns them."""
+        X, U = np.asarray(state, dtype=np.float64), np.asarray(control, dtype=np.float64)
+        if X.ndim != 2 or U.ndim != 2 or X.shape[0] != self.N or U.shape[0] != self.M or X.shape[1] != U.shape[1]:
+            raise TypeError("parallel_cost takes (n x k) states and (m x k) controls")
+        return np.array([float(self._aux(X[:, j], U[:, j])["par_cost"]) for j in range(X.shape[1])])
+
+    def dynamics_hessian_fxx(self, state, control):
+        f = self._aux(state, control)["fxx"]
+        return f[0], f[1], f[2]
+
+    def max_constraints_violation(self, state, control):
+        return float(self._aux(state, control)["viol"])
+
+    def update_lambda(self, state, control):
+        self.constraints_obj.lambda_ = self._aux(state, control)["lam_new"]
+
+    def constraints(self, state, control):
+        return self._aux(state, control)["cval"]
 
 
 def _bicycle_node(cons_cls):

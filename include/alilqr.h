@@ -245,6 +245,29 @@ int32_t alilqr_linearize_batch(const alilqr_problem* p,
                                double* lx, double* lu, double* lxx, double* luu,
                                void* stream);
 
+/*
+ * The remaining per-node calls of the reference's node / constraint objects, on B*(H+1) independent points
+ * (inputs as in alilqr_linearize_batch; every output may be NULL):
+ *   cval    [B][H+1][c]       node.constraints() / constraints_obj.constrains(x,u) / Constraints::constraints(x,u)
+ *                             (lat_bicycle_node.py:127-133, linear_constraints.py:13-16, linear_constraints.h:176-181,
+ *                              quadratic_constraints.h:15-27)
+ *   lam_new [B][H+1][c]       multipliers after one update_lambda() at the point
+ *                             (lat_bicycle_node.py:162-165, constraints.py:106-110, constraints.h:878-887)
+ *   viol    [B][H+1]          the node's term of the violation measure: || max(-lam/mu, c) ||_2 (ilqr.py:186-192),
+ *                             max_violation / max_constraints_violation = || max(c, 0) ||_inf
+ *                             (constraints.py:115-119, constraints.h:1027-1040)
+ *   par_cost [B][H+1]         NEW_AL only: one column of NewILQRNode::parallel_cost (new_bicycle_node.h:768-795,
+ *                             constraints.h:558-580)
+ *   fxx     [B][H+1][3][n][n] NEW_AL only: dynamics_hessian_fxx, the Hessians of the first three state rows
+ *                             (new_bicycle_node.h:605-650, new_lat_bicycle_node.h:128-163)
+ */
+int32_t alilqr_node_aux_batch(const alilqr_problem* p,
+                              const double* x, const double* u,
+                              const double* lam, const double* mu,
+                              const double* goals, const double* Q, const double* R, const double* cons,
+                              double* cval, double* lam_new, double* viol, double* par_cost, double* fxx,
+                              void* stream);
+
 /* Release every cached device workspace of the calling process. */
 int32_t alilqr_release(void);
 

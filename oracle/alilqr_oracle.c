@@ -912,3 +912,41 @@ int32_t oracle_linearize_batch(const alilqr_problem* p,
   }
   return ALILQR_OK;
 }
+
+int32_t oracle_node_aux_batch(const alilqr_problem* p,
+                              const double* x, const double* u,
+                              const double* lam, const double* mu,
+                              const double* goals, const double* Q, const double* R, const double* cons,
+                              double* viol, double* par_cost, double* fxx) {
+  if (!p || !x || !u || !goals || !Q || !R || !cons) return ALILQR_E_ARG;
+  if (p->mode == ALILQR_MODE_NEW_AL) return or_new_node_aux(p, x, u, lam, mu, goals, Q, R, cons, viol, par_cost, fxx);
+  if (par_cost || fxx) return ALILQR_E_ARG;
+  int B = p->batch, H = p->horizon, n = p->n, m = p->m, c = p->c;
+  size_t xs = (size_t)(H + 1) * n;
+  for (int b = 0; b < B; ++b) {
+    const double* g = goals + ((p->goal_batch > 1) ? (size_t)b * xs : 0);
+    for (int t = 0; t <= H; ++t) {
+      size_t i = (size_t)b * (H + 1) + t;
+      or_node nd;
+      or_node_init(&nd, p, t, g, Q, R, cons);
+      memcpy(nd.state, x + i * n, sizeof(double) * n);
+      memcpy(nd.control, u + i * m, sizeof(double) * m);
+      if (lam) memcpy(nd.lam, lam + i * c, sizeof(double) * c);
+      if (mu) nd.mu = mu[b];
+      if (!viol) continue;
+      if (p->mode == ALILQR_MODE_LEGACY) {                  /* one node's term of ilqr.py:186-192 */
+        double cv[OR_NC], ss = 0.0;
+        legacy_constraints(&nd, cv);
+        for (int q = 0; q < c; ++q) {
+          double one = fmax(-nd.lam[q] / nd.mu, cv[q]);
+          ss += one * one;
+        }
+        viol[i] = sqrt(ss);
+      } else {
+        (void)node_cost(&nd);                               /* the node wraps its state on its first cost() call */
+        viol[i] = fast_max_violation(&nd);
+      }
+    }
+  }
+  return ALILQR_OK;
+}

@@ -71,6 +71,13 @@ int32_t oracle_linearize_batch(const alilqr_problem* p,
                                double* lx, double* lu, double* lxx, double* luu,
                                double* cval, double* lam_new, double* xnorm);
 
+/* Same argument list as alilqr_node_aux_batch with host pointers (cval and lam_new come from oracle_linearize_batch). */
+int32_t oracle_node_aux_batch(const alilqr_problem* p,
+                              const double* x, const double* u,
+                              const double* lam, const double* mu,
+                              const double* goals, const double* Q, const double* R, const double* cons,
+                              double* viol, double* par_cost, double* fxx);
+
 int32_t oracle_max_threads(void);
 
 #ifdef __cplusplus

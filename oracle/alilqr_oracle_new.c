@@ -759,3 +759,26 @@ int32_t or_new_linearize(const alilqr_problem* p,
   }
   return ALILQR_OK;
 }
+
+int32_t or_new_node_aux(const alilqr_problem* p,
+                        const double* x, const double* u,
+                        const double* lam, const double* mu,
+                        const double* goals, const double* Q, const double* R, const double* cons,
+                        double* viol, double* par_cost, double* fxx) {
+  int B = p->batch, H = p->horizon, n = p->n, m = p->m, c = p->c;
+  size_t xs = (size_t)(H + 1) * n, nn = (size_t)n * n;
+  for (int b = 0; b < B; ++b) {
+    const double* g = goals + ((p->goal_batch > 1) ? (size_t)b * xs : 0);
+    for (int t = 0; t <= H; ++t) {
+      size_t i = (size_t)b * (H + 1) + t;
+      nw_node nd;
+      nw_node_init(&nd, p, t, g, Q, R, cons);
+      if (lam) memcpy(nd.lam, lam + i * c, sizeof(double) * c);
+      if (mu) nd.mu = mu[b];
+      if (viol) viol[i] = nw_max_violation(&nd, x + i * n, u + i * m);
+      if (par_cost) par_cost[i] = nw_par_cost(&nd, x + i * n, u + i * m);
+      if (fxx) nw_fxx(&nd, x + i * n, u + i * m, fxx + (i * 3 + 0) * nn, fxx + (i * 3 + 1) * nn, fxx + (i * 3 + 2) * nn);
+    }
+  }
+  return ALILQR_OK;
+}

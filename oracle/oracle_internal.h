@@ -52,4 +52,9 @@ int32_t or_new_linearize(const alilqr_problem* p,
                          double* f, double* fx, double* fu, double* l,
                          double* lx, double* lu, double* lxx, double* luu,
                          double* cval, double* lam_new, double* xnorm);
+int32_t or_new_node_aux(const alilqr_problem* p,
+                        const double* x, const double* u,
+                        const double* lam, const double* mu,
+                        const double* goals, const double* Q, const double* R, const double* cons,
+                        double* viol, double* par_cost, double* fxx);
 #endif

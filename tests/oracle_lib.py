@@ -89,3 +89,18 @@ def linearize_batch(desc, x, u, lam, mu, goals, Q, R, cons):
     if rc != 0:
         raise RuntimeError(f"oracle_linearize_batch failed: {rc}")
     return out
+
+
+def node_aux_batch(desc, x, u, lam, mu, goals, Q, R, cons):
+    B, H, n = desc.batch, desc.horizon, desc.n
+    new_al = desc.mode == capi.MODES["new_al"]
+    out = dict(viol=np.zeros((B, H + 1)))
+    if new_al:
+        out.update(par_cost=np.zeros((B, H + 1)), fxx=np.zeros((B, H + 1, 3, n, n)))
+    args = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, u, lam, mu, goals, Q, R, cons)]
+    lib().oracle_node_aux_batch.restype = C.c_int32
+    rc = lib().oracle_node_aux_batch(C.byref(desc), *[_p(a) for a in args], _p(out["viol"]), _p(out.get("par_cost")),
+                                     _p(out.get("fxx")))
+    if rc != 0:
+        raise RuntimeError(f"oracle_node_aux_batch failed: {rc}")
+    return out

@@ -102,6 +102,17 @@ def test_pybind_shaped_solver_runs_the_reference_script_flow():
     assert gu.rel_err(f, x[:, 1]) < 1e-14
     fx, fu = nodes[0].dynamics_jacobian(x[:, 0], u[:, 0])
     assert fx.shape == (6, 6) and fu.shape == (6, 2)
+    # the rest of the per-node surface (node_bind.h:43-93)
+    F0, F1, F2 = nodes[0].dynamics_hessian_fxx(x[:, 5], u[:, 5])
+    assert F0.shape == (6, 6) and np.allclose(F0, F0.T) and F0[2, 2] != 0 and F2[3, 3] != 0
+    assert nodes[5].max_constraints_violation(x[:, 5], u[:, 5]) < 1e-4
+    X5, U5 = np.tile(x[:, 5:6], (1, 5)), np.tile(u[:, 5:6], (1, 5))
+    pc = nodes[5].parallel_cost(X5, U5)
+    assert pc.shape == (5,) and abs(pc[0] - nodes[5].cost(x[:, 5], u[:, 5])) <= 1e-9 * abs(pc[0])
+    before = nodes[5].constraints_obj.lambda_.copy()
+    nodes[5].update_lambda(x[:, 5], u[:, 5])
+    cv = nodes[5].constraints(x[:, 5], u[:, 5])
+    assert np.allclose(nodes[5].constraints_obj.lambda_, np.minimum(before - nodes[5].constraints_obj.mu * cv, 0.0))
 
 
 def test_pybind_shaped_quadratic_constraints_flow():

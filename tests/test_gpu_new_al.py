@@ -131,3 +131,11 @@ def test_new_al_node_kernel_matches_oracle(model, quad):
     o = to_np(batch.linearize_batch(desc, x, u, lam, MU, goals, Q, R, cons))
     for key in ("f", "fx", "fu", "l", "lx", "lu", "lxx", "luu"):
         assert gu.rel_err(o[key][:, 0], ref[key][:, 0]) < 1e-11, key
+    # the remaining per-node calls: constraints, update_lambda, max_constraints_violation, parallel_cost, f_xx
+    aux = to_np(batch.node_aux_batch(desc, x, u, lam, MU, goals, Q, R, cons))
+    raux = ol.node_aux_batch(desc, x, u, lam, MU, goals, Q, R, cons)
+    assert gu.rel_err(aux["cval"][:, 0], ref["cval"][:, 0]) < 1e-12
+    assert gu.rel_err(aux["lam_new"][:, 0], ref["lam_new"][:, 0]) < 1e-12
+    for key in ("viol", "par_cost", "fxx"):
+        assert gu.rel_err(aux[key][:, 0], raux[key][:, 0]) < 1e-11, key
+    assert np.abs(aux["fxx"][:, 0]).max() > 0

@@ -224,3 +224,34 @@ def test_solves_on_different_streams_overlap_and_match():
         o = to_np(sv.out)
         for k in ("x", "u", "cost", "status"):
             assert np.array_equal(o[k], ref[k]), k
+
+
+@pytest.mark.parametrize("tag,model,mode", [("legacy_lat", "lat", "legacy"), ("legacy_dyn", "dyn", "legacy"),
+                                             ("fast_box", "dyn_mid", "fast"), ("fast_linear", "dyn_mid", "fast")])
+def test_node_aux_kernel_matches_reference_vectors(tag, model, mode):
+    """alilqr_node_aux_batch: constraint values, one multiplier update and the violation term against the
+    reference's golden points (and the oracle for the legacy violation term, which the goldens do not hold)."""
+    k = gu.load("nodes_kat")
+    pre = tag + "_"
+    X, U, LAM, MU = k[pre + "X"], k[pre + "U"], k[pre + "LAM"], k[pre + "MU"]
+    N = X.shape[0]
+    if mode == "legacy":
+        cons = capi.pack_box(k[pre + "state_min"], k[pre + "state_max"], k[pre + "control_min"], k[pre + "control_max"])
+        desc = capi.make_problem(model, mode, 1, N, float(k[pre + "L"]), float(k[pre + "dt"]), v=float(k[pre + "v"]),
+                                 k=float(k[pre + "k"]))
+    else:
+        cons = capi.pack_linear(k[pre + "A"], k[pre + "B"], k[pre + "C"])
+        desc = capi.make_problem(model, mode, 1, N, float(k[pre + "L"]), float(k[pre + "dt"]), k=float(k[pre + "k"]),
+                                 c=k[pre + "A"].shape[0])
+    n, m = desc.n, desc.m
+    goals = np.tile(k[pre + "goal"], (2, 1))
+    x = np.zeros((N, 2, n)); x[:, 0] = X
+    u = np.zeros((N, 2, m)); u[:, 0] = U
+    lam = np.zeros((N, 2, desc.c)); lam[:, 0] = LAM
+    o = to_np(batch.node_aux_batch(desc, x, u, lam, MU, goals, k[pre + "Q"], k[pre + "R"], cons))
+    assert gu.rel_err(o["cval"][:, 0], k[pre + "cons"]) < 1e-12
+    assert gu.rel_err(o["lam_new"][:, 0], k[pre + "lam_new"]) < 1e-12
+    ref = ol.node_aux_batch(desc, x, u, lam, MU, goals, k[pre + "Q"], k[pre + "R"], cons)
+    assert gu.rel_err(o["viol"][:, 0], ref["viol"][:, 0]) < 1e-12
+    if mode == "fast":
+        assert gu.rel_err(o["viol"][:, 0], k[pre + "viol"]) < 1e-12

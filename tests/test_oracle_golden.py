@@ -74,3 +74,20 @@ def test_node_functions_match_reference(tag, model, mode):
     for key, okey in (("f", "f"), ("fx", "fx"), ("fu", "fu"), ("l", "l"), ("lx", "lx"), ("lu", "lu"),
                       ("lxx", "lxx"), ("luu", "luu"), ("cons", "cval"), ("lam_new", "lam_new")):
         assert gu.rel_err(out[okey][:, 0], k[pre + key]) < 1e-12, (tag, key)
+
+
+@pytest.mark.parametrize("tag", ["fast_box", "fast_linear"])
+def test_node_violation_term_matches_reference(tag):
+    """Constraints.max_violation (cilqr/constraints.py:115-119) at the golden points."""
+    k = gu.load("nodes_kat")
+    pre = tag + "_"
+    X, U, LAM, MU = k[pre + "X"], k[pre + "U"], k[pre + "LAM"], k[pre + "MU"]
+    N = X.shape[0]
+    cons = capi.pack_linear(k[pre + "A"], k[pre + "B"], k[pre + "C"])
+    desc = capi.make_problem("dyn_mid", "fast", 1, N, float(k[pre + "L"]), float(k[pre + "dt"]), k=float(k[pre + "k"]),
+                             c=k[pre + "A"].shape[0])
+    x = np.zeros((N, 2, 6)); x[:, 0] = X
+    u = np.zeros((N, 2, 2)); u[:, 0] = U
+    lam = np.zeros((N, 2, desc.c)); lam[:, 0] = LAM
+    out = ol.node_aux_batch(desc, x, u, lam, MU, np.tile(k[pre + "goal"], (2, 1)), k[pre + "Q"], k[pre + "R"], cons)
+    assert gu.rel_err(out["viol"][:, 0], k[pre + "viol"]) < 1e-12
