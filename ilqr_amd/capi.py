@@ -70,7 +70,7 @@ def default_params(mode):
     raise ValueError(f"unknown solver mode {mode}")
 
 
-CONS_LINEAR, CONS_QUADRATIC = 0, 1
+CONS_LINEAR, CONS_QUADRATIC, CONS_EQUALITY = 0, 1, 2
 
 
 def make_problem(model, mode, horizon, batch, L, dt, v=0.0, k=0.0, c=None,
@@ -107,7 +107,7 @@ def cons_words(desc):
     if desc.mode == MODES["legacy"]:
         return 2 * desc.n + 2 * desc.m
     w = desc.c * (desc.n + desc.m + 1)
-    if desc.cons_kind == CONS_QUADRATIC:
+    if desc.cons_kind & CONS_QUADRATIC:
         w += desc.c * desc.n * desc.n
     return w
 

@@ -69,8 +69,11 @@ int32_t check_problem(const alilqr_problem* p, Dims* d) {
   if (p->horizon < 1 || p->batch < 0) { set_err("horizon must be >= 1 and batch >= 0"); return ALILQR_E_ARG; }
   if (p->goal_batch != 1 && p->goal_batch != p->batch) { set_err("goal_batch must be 1 or batch"); return ALILQR_E_ARG; }
   if (p->table_nodes != 1 && p->table_nodes != p->horizon + 1) { set_err("table_nodes must be 1 or horizon+1"); return ALILQR_E_ARG; }
-  if (p->cons_kind != ALILQR_CONS_LINEAR && p->cons_kind != ALILQR_CONS_QUADRATIC) { set_err("unknown cons_kind"); return ALILQR_E_ARG; }
-  if (p->cons_kind == ALILQR_CONS_QUADRATIC && p->mode != ALILQR_MODE_NEW_AL) {
+  if (p->cons_kind < 0 || p->cons_kind > (ALILQR_CONS_QUADRATIC | ALILQR_CONS_EQUALITY)) { set_err("unknown cons_kind"); return ALILQR_E_ARG; }
+  if ((p->cons_kind & ALILQR_CONS_EQUALITY) && p->mode == ALILQR_MODE_LEGACY) {
+    set_err("equality tables are defined for FAST and NEW_AL"); return ALILQR_E_ARG;
+  }
+  if ((p->cons_kind & ALILQR_CONS_QUADRATIC) && p->mode != ALILQR_MODE_NEW_AL) {
     set_err("quadratic constraint tables are defined for NEW_AL"); return ALILQR_E_ARG;
   }
   if (p->mode == ALILQR_MODE_LEGACY) {
@@ -120,7 +123,7 @@ struct Plan {
 
 // kernel instantiation of a NEW_AL descriptor: constraint kind x rectangle activation
 int new_al_variant(const alilqr_problem* p, bool rect) {
-  const bool quad = (p->cons_kind == ALILQR_CONS_QUADRATIC);
+  const bool quad = ((p->cons_kind & ALILQR_CONS_QUADRATIC) != 0);
   if (quad) return rect ? alilqr::kModeNewAlQuadRect : alilqr::kModeNewAlQuad;
   return rect ? alilqr::kModeNewAlRect : ALILQR_MODE_NEW_AL;
 }
@@ -183,7 +186,7 @@ int32_t launch_g(const alilqr::KArgs& ka, int G, int waves, hipStream_t st) {
 // node evaluation kernel (alilqr_linearize_batch): one thread per node
 // ---------------------------------------------------------------------------
 struct LArgs {
-  int B, H, C, goal_batch, table_nodes, quad;
+  int B, H, C, goal_batch, table_nodes, quad, eq;
   alilqr::ModelConst mc;
   const double *x, *u, *lam, *mu, *goals, *Q, *R, *cons;
   double *f, *fx, *fu, *l, *lx, *lu, *lxx, *luu;
@@ -207,6 +210,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(LArgs a) {
   ka.C = a.C;
   ka.qdiag = 0;
   ka.quad = a.quad;
+  ka.eq = a.eq;
   ka.quad_rows = ~0ull;   // no row is skipped here: an all-zero matrix contributes exact zeros
   double x[N], u[M], xn[N], ac[MD::NA], bc[MD::NB], S[N][N], Bm[N][M];
 #pragma unroll
@@ -414,7 +418,8 @@ int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
   ka.B = p->batch; ka.NG = pl.NG; ka.H = p->horizon; ka.C = p->c;
   ka.goal_batch = p->goal_batch; ka.table_nodes = p->table_nodes;
   ka.mc = {p->L, p->dt, p->v, p->k};
-  ka.quad = (p->cons_kind == ALILQR_CONS_QUADRATIC) ? 1 : 0;
+  ka.quad = ((p->cons_kind & ALILQR_CONS_QUADRATIC) != 0) ? 1 : 0;
+  ka.eq = (p->cons_kind & ALILQR_CONS_EQUALITY) ? 1 : 0;
   ka.prm = p->prm;
   ka.x0 = x0; ka.goals = goals; ka.Q = Q; ka.R = R; ka.cons = cons; ka.u_off = u_offset;
   if (rect) { ka.left_obs = ex->left_obs; ka.right_obs = ex->right_obs; ka.n_left = n_left; ka.n_right = n_right; ka.first_row = ex->first_row; }
@@ -478,7 +483,8 @@ static int32_t node_eval(const alilqr_problem* p,
   }
   LArgs a{};
   a.B = p->batch; a.H = p->horizon; a.C = p->c; a.goal_batch = p->goal_batch; a.table_nodes = p->table_nodes;
-  a.quad = (p->cons_kind == ALILQR_CONS_QUADRATIC) ? 1 : 0;
+  a.quad = ((p->cons_kind & ALILQR_CONS_QUADRATIC) != 0) ? 1 : 0;
+  a.eq = (p->cons_kind & ALILQR_CONS_EQUALITY) ? 1 : 0;
   a.mc = {p->L, p->dt, p->v, p->k};
   a.x = x; a.u = u; a.lam = lam; a.mu = mu; a.goals = goals; a.Q = Q; a.R = R; a.cons = cons;
   a.cval = cval; a.lam_new = lam_new; a.viol = viol; a.pcost = pcost; a.fxx = fxx;

@@ -63,6 +63,7 @@ __device__ __forceinline__ ctab as_ctab(const double* p) {
 struct KArgs {
   int B, NG, H, C, goal_batch, table_nodes;
   int qdiag;                  // every Q table is diagonal (set in the kernel prologue)
+  int eq;                     // equality table: no projection of lambda - mu c (ALILQR_CONS_EQUALITY)
   int quad;                   // constraint tables carry per-row quadratic terms (NEW_AL, ALILQR_CONS_QUADRATIC)
   unsigned long long quad_rows;   // rows whose quadratic matrix is not all zero, over all tables (kernel prologue)
   ModelConst mc;
@@ -480,7 +481,7 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
     for (int i = 0; i < a.C; ++i) {
       double l = lam[i * ls];
       double f = l - mu * cval(a, tab, x, u, i);
-      double lp = fmin(f, 0.0);
+      double lp = a.eq ? f : fmin(f, 0.0);          // constraints.py:61-62
       pp += lp * lp;
       ll += l * l;
     }
@@ -507,8 +508,8 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
       for (int j = 0; j < M; ++j) hu[i][j] = 0.0;
     for (int i = 0; i < a.C; ++i) {
       double f = lam[i * ls] - mu * cval(a, tab, x, u, i);
-      double lp = fmin(f, 0.0);
-      double pj = (f > 0.0) ? 0.0 : 1.0;
+      double lp = a.eq ? f : fmin(f, 0.0);          // constraints.py:70-73, 91-94
+      double pj = a.eq ? 1.0 : ((f > 0.0) ? 0.0 : 1.0);
       double pa[N], pb[M];
 #pragma unroll
       for (int j = 0; j < N; ++j) { pa[j] = pj * A[i * N + j]; jx[j] += pa[j] * lp; }
@@ -562,7 +563,8 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
                                        double* lam, size_t ls, double mu) {
     for (int i = 0; i < a.C; ++i) {
       double c = cval(a, tab, x, u, i);
-      lam[i * ls] = fmin(lam[i * ls] - mu * c, 0.0);
+      const double f = lam[i * ls] - mu * c;
+      lam[i * ls] = a.eq ? f : fmin(f, 0.0);
     }
   }
 };
@@ -650,7 +652,8 @@ struct NewAlOps {
     double pp = 0.0, ll = 0.0;
     for (int i = 0; i < a.C; ++i) {
       double l = lam[i * ls];
-      double lp = fmin(l - mu * cval(a, tab, x, u, i, lam, ls), 0.0);
+      const double f = l - mu * cval(a, tab, x, u, i, lam, ls);
+      double lp = a.eq ? f : fmin(f, 0.0);          // constraints.h:520-528
       pp += lp * lp;
       ll += l * l;
     }
@@ -667,7 +670,8 @@ struct NewAlOps {
     for (int j = 0; j < M; ++j) cr += (R[j * M + j] * u[j]) * u[j];
     for (int i = 0; i < a.C; ++i) {
       double l = lam[i * ls];
-      double pr = fmin(l - mu * par_cval(a, tab, x, u, i, lam, ls), 0.0);
+      const double f = l - mu * par_cval(a, tab, x, u, i, lam, ls);
+      double pr = a.eq ? f : fmin(f, 0.0);
       al += pr * pr - l * l;
     }
     al = 0.5 / mu * al;
@@ -693,8 +697,9 @@ struct NewAlOps {
 #pragma unroll
       for (int j = 0; j < M; ++j) hu[i][j] = 0.0;
     for (int i = 0; i < a.C; ++i) {
-      double lp = fmin(lam[i * ls] - mu * cval(a, tab, x, u, i, lam, ls), 0.0);
-      double on = (lp >= 0.0) ? 0.0 : 1.0;
+      const double fi = lam[i * ls] - mu * cval(a, tab, x, u, i, lam, ls);
+      double lp = a.eq ? fi : fmin(fi, 0.0);        // the equality branch works on the factor itself (constraints.h:673-676)
+      double on = a.eq ? 1.0 : ((lp >= 0.0) ? 0.0 : 1.0);
       double cx[N], pa[N], pb[M];
 #pragma unroll
       for (int j = 0; j < N; ++j) cx[j] = a_ij(a, A, lam, ls, i, j);
@@ -720,11 +725,11 @@ struct NewAlOps {
 #pragma unroll
       for (int p = 0; p < N; ++p)
 #pragma unroll
-        for (int q = 0; q < N; ++q) hx[p][q] += (mu * pa[p]) * cx[q];
+        for (int q = 0; q < N; ++q) hx[p][q] += a.eq ? (cx[p] * cx[q]) : ((mu * pa[p]) * cx[q]);   // mu (cx'cx) vs (mu P cx)'cx, constraints.h:791-802
 #pragma unroll
       for (int p = 0; p < M; ++p)
 #pragma unroll
-        for (int q = 0; q < M; ++q) hu[p][q] += (mu * pb[p]) * Bm[i * M + q];
+        for (int q = 0; q < M; ++q) hu[p][q] += a.eq ? (Bm[i * M + p] * Bm[i * M + q]) : ((mu * pb[p]) * Bm[i * M + q]);
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -733,7 +738,7 @@ struct NewAlOps {
       for (int j = 0; j < N; ++j) s += (2 * Q[i * N + j]) * e[j];
       rec[(LL::oLx + i) * rs] = s + (-jx[i]);
 #pragma unroll
-      for (int j = 0; j < N; ++j) rec[(LL::oLxx + i * N + j) * rs] = 2 * Q[i * N + j] + (hx[i][j] - 1.0 * tq[i][j]);
+      for (int j = 0; j < N; ++j) rec[(LL::oLxx + i * N + j) * rs] = 2 * Q[i * N + j] + ((a.eq ? mu * hx[i][j] : hx[i][j]) - 1.0 * tq[i][j]);
     }
 #pragma unroll
     for (int i = 0; i < M; ++i) {
@@ -742,7 +747,7 @@ struct NewAlOps {
       for (int j = 0; j < M; ++j) s += (2 * R[i * M + j]) * u[j];
       rec[(LL::oLu + i) * rs] = s + (-ju[i]);
 #pragma unroll
-      for (int j = 0; j < M; ++j) rec[(LL::oLuu + i * M + j) * rs] = 2 * R[i * M + j] + hu[i][j];
+      for (int j = 0; j < M; ++j) rec[(LL::oLuu + i * M + j) * rs] = 2 * R[i * M + j] + (a.eq ? mu * hu[i][j] : hu[i][j]);
     }
   }
   __device__ static double violation(const KArgs& a, ctab tab, const double* x, const double* u,
@@ -762,7 +767,8 @@ struct NewAlOps {
                                        double* lam, size_t ls, double mu) {
     for (int i = 0; i < a.C; ++i) {
       double c = cval(a, tab, x, u, i, lam, ls);
-      lam[i * ls] = fmin(lam[i * ls] - mu * c, 0.0);
+      const double f = lam[i * ls] - mu * c;
+      lam[i * ls] = a.eq ? f : fmin(f, 0.0);        // constraints.h:878-887
     }
   }
 };

@@ -236,7 +236,8 @@ class _NodeCommon(ABC):
         lam, mu = self.multipliers()
         n, m = self._state_dim, self._control_dim
         L, dt, v, k = self.model_constants()
-        desc = capi.make_problem(self.MODEL, self.MODE, 1, 1, L, dt, v=v, k=k, c=len(lam))
+        desc = capi.make_problem(self.MODEL, self.MODE, 1, 1, L, dt, v=v, k=k, c=len(lam),
+                                 cons_kind=self.cons_kind() if hasattr(self, "cons_kind") else capi.CONS_LINEAR)
         xs = np.zeros((1, 2, n)); xs[0, 0] = x
         us = np.zeros((1, 2, m)); us[0, 0] = u
         ls = np.zeros((1, 2, len(lam))); ls[0, 0] = lam
@@ -397,11 +398,12 @@ class FastILQRNode(_NodeCommon):
         c = self.constraints_obj
         if not isinstance(c, LinearConstraints):
             raise NotImplementedError("the GPU solve path takes linear constraint tables (LinearConstraints / BoxConstraint)")
-        if c.is_equality:
-            raise NotImplementedError("equality constraints are not on the GPU solve path yet")
         if c.A.shape != (c.constraint_dim, self._state_dim) or c.B.shape != (c.constraint_dim, self._control_dim):
             raise ValueError("Invalid constraint table dimension")
         return capi.pack_linear(c.A, c.B, c.C)
+
+    def cons_kind(self):
+        return capi.CONS_EQUALITY if self.constraints_obj.is_equality else capi.CONS_LINEAR
 
     def multipliers(self):
         return np.asarray(self.constraints_obj.lambda_, dtype=np.float64), float(self.constraints_obj.mu)

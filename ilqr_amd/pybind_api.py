@@ -104,7 +104,7 @@ class _LinearConstraints(_Constraints):
     def __init__(self, A, B, C, is_equality=False):
         super().__init__()
         if is_equality:
-            raise NotImplementedError("equality constraints are not on the GPU path")
+            self.KIND = capi.CONS_LINEAR | capi.CONS_EQUALITY
         self.A = _mat(A, self.C, self.N, "A")
         self.B = _mat(B, self.C, self.M, "B")
         self.Cv = _vec(C, self.C, "C")
@@ -135,7 +135,7 @@ class _QuadraticConstraints(_Constraints):
     def __init__(self, Q, A, B, C, is_equality=False):
         super().__init__()
         if is_equality:
-            raise NotImplementedError("equality constraints are not on the GPU path")
+            self.KIND = capi.CONS_QUADRATIC | capi.CONS_EQUALITY
         Q = list(Q)
         if len(Q) != self.C:
             raise TypeError(f"Q: expected {self.C} matrices, got {len(Q)}")
@@ -327,6 +327,8 @@ class _NewALILQR:
             raise ValueError("L, dt, v, k must be the same on every node of a trajectory")
         Qs, Rs = [nd.Q for nd in nodes], [nd.R for nd in nodes]
         Ts = [nd.constraints_obj.table() for nd in nodes]
+        if any(nd.constraints_obj.KIND != nd0.constraints_obj.KIND for nd in nodes):
+            raise ValueError("one constraint kind per trajectory")
         shared = all(np.array_equal(q, Qs[0]) for q in Qs) and all(np.array_equal(r, Rs[0]) for r in Rs) \
             and all(np.array_equal(t, Ts[0]) for t in Ts)
         tn = 1 if shared else len(nodes)

@@ -43,6 +43,8 @@ class _SolverBase:
             raise TypeError("all nodes of a trajectory must be of the same node class")
         if nodes[0].MODE != self.MODE:
             raise TypeError(f"{type(self).__name__} takes {'ILQRNode' if self.MODE == 'legacy' else 'FastILQRNode'} nodes")
+        if hasattr(nodes[0], "cons_kind") and any(nd.cons_kind() != nodes[0].cons_kind() for nd in nodes):
+            raise ValueError("equality and inequality tables cannot be mixed along a trajectory")
         consts = nodes[0].model_constants()
         if any(nd.model_constants() != consts for nd in nodes):
             raise ValueError("L, dt, v, k must be the same on every node of a trajectory")
@@ -53,7 +55,8 @@ class _SolverBase:
         lam0, _ = nodes[0].multipliers()
         L, dt, v, k = consts
         desc = capi.make_problem(kind.MODEL, self.MODE, self.horizon, batch_size, L, dt, v=v, k=k, c=len(lam0),
-                                 table_nodes=table_nodes, params=prm)
+                                 table_nodes=table_nodes, params=prm,
+                                 cons_kind=nodes[0].cons_kind() if hasattr(nodes[0], "cons_kind") else capi.CONS_LINEAR)
         goals = np.stack([np.asarray(nd.goal, dtype=np.float64) for nd in nodes])[None]
         return desc, goals, Q, R, cons
 

@@ -60,7 +60,11 @@ enum alilqr_mode {
  */
 enum alilqr_cons_kind {
   ALILQR_CONS_LINEAR = 0,
-  ALILQR_CONS_QUADRATIC = 1
+  ALILQR_CONS_QUADRATIC = 1,
+  /* flag, OR-ed into the kind: the table holds EQUALITY rows c(x,u) = 0 (is_equality of the reference's
+   * constraint classes: constraints.py:59-110, constraints.h:520-523,673-676,791-795,880-882): no projection of
+   * lambda - mu c, multiplier update lambda <- lambda - mu c; FAST and NEW_AL */
+  ALILQR_CONS_EQUALITY = 2
 };
 
 enum alilqr_status {

@@ -359,7 +359,7 @@ static double fast_al_cost(or_node* nd) {                  /* constraints.py:59-
   double pp = 0.0, ll = 0.0;
   for (int i = 0; i < nd->c; ++i) {
     double f = nd->lam[i] - nd->mu * nd->cc[i];
-    double lp = fmin(f, 0.0);
+    double lp = nd->eq ? f : fmin(f, 0.0);       /* constraints.py:61-62 */
     pp += lp * lp;
   }
   for (int i = 0; i < nd->c; ++i) ll += nd->lam[i] * nd->lam[i];
@@ -394,8 +394,8 @@ static void fast_cost_jacobian(or_node* nd, double* Jx, double* Ju) {  /* fast_b
   double lp[OR_NC], pj[OR_NC];
   for (int i = 0; i < nd->c; ++i) {
     double f = nd->lam[i] - nd->mu * nd->cc[i];
-    lp[i] = fmin(f, 0.0);
-    pj[i] = (f > 0.0) ? 0.0 : 1.0;
+    lp[i] = nd->eq ? f : fmin(f, 0.0);            /* constraints.py:70-73 */
+    pj[i] = nd->eq ? 1.0 : ((f > 0.0) ? 0.0 : 1.0);
   }
   for (int j = 0; j < n; ++j) {
     double s = 0.0;
@@ -417,7 +417,7 @@ static void fast_cost_hessian(or_node* nd, double* Hx, double* Hu) {   /* fast_b
   double pj[OR_NC];
   for (int i = 0; i < nd->c; ++i) {
     double f = nd->lam[i] - nd->mu * nd->cc[i];
-    pj[i] = (f > 0.0) ? 0.0 : 1.0;
+    pj[i] = nd->eq ? 1.0 : ((f > 0.0) ? 0.0 : 1.0);   /* constraints.py:91-94 */
   }
   for (int a = 0; a < n; ++a)
     for (int b = 0; b < n; ++b) {
@@ -443,7 +443,10 @@ static double fast_max_violation(or_node* nd) {            /* constraints.py:115
   return v;
 }
 static void fast_update_lambda(or_node* nd) {              /* constraints.py:106-110: uses the cached c */
-  for (int i = 0; i < nd->c; ++i) nd->lam[i] = fmin(nd->lam[i] - nd->mu * nd->cc[i], 0.0);
+  for (int i = 0; i < nd->c; ++i) {
+    double f = nd->lam[i] - nd->mu * nd->cc[i];
+    nd->lam[i] = nd->eq ? f : fmin(f, 0.0);
+  }
 }
 
 /* ------------------------------------------------------------------------ */
@@ -463,6 +466,7 @@ void or_node_init(or_node* nd, const alilqr_problem* p, int t,
   int n = p->n, m = p->m, c = p->c;
   int tt = (p->table_nodes > 1) ? t : 0;
   nd->model = p->model; nd->mode = p->mode; nd->n = n; nd->m = m; nd->c = c;
+  nd->eq = (p->cons_kind & ALILQR_CONS_EQUALITY) ? 1 : 0;
   nd->L = p->L; nd->dt = p->dt; nd->v = p->v; nd->k = p->k;
   nd->Q = Q + (size_t)tt * n * n;
   nd->R = R + (size_t)tt * m * m;

@@ -10,7 +10,6 @@
  * by review against the cited lines and by the node / constraint formulas it
  * shares with the Python generations (tests compare those).
  *
- * Not restated (the reference path marked "next"): equality constraints.
  */
 #define _GNU_SOURCE   /* M_PI under -std=c11 */
 #include "alilqr_oracle.h"
@@ -29,6 +28,7 @@ typedef struct nw_node {
   double Aown[OR_NC * OR_NX], Cown[OR_NC];   /* the node's own copy of A and C (constraints are copied into the node,
                                                 new_bicycle_node.h:169-170); A and C point here */
   int cur_index;                       /* current_constraints_index_ (constraints.h:1191) */
+  int eq;                              /* is_equality_ */
   const double* Qc;                    /* quadratic table: c matrices n x n, or NULL (quadratic_constraints.h:94) */
   double goal[OR_NX];
   double lam[OR_NC], mu;
@@ -229,7 +229,8 @@ static double nw_al_cost(nw_node* nd, const double* x, const double* u) {
   nw_constraints(nd, x, u, nd->c_);
   double pp = 0.0, ll = 0.0;
   for (int i = 0; i < nd->c; ++i) {
-    nd->lp_[i] = fmin(nd->lam[i] - nd->mu * nd->c_[i], 0.0);
+    double f = nd->lam[i] - nd->mu * nd->c_[i];
+    nd->lp_[i] = nd->eq ? f : fmin(f, 0.0);     /* constraints.h:520-528; lp_ doubles as the equality factor */
     pp += nd->lp_[i] * nd->lp_[i];
   }
   for (int i = 0; i < nd->c; ++i) ll += nd->lam[i] * nd->lam[i];
@@ -256,7 +257,8 @@ static double nw_par_cost(const nw_node* nd, const double* x, const double* u) {
   for (int j = 0; j < nd->m; ++j) cr += (nd->R[j * nd->m + j] * u[j]) * u[j];
   nw_par_constraints(nd, x, u, c);
   for (int i = 0; i < nd->c; ++i) {
-    double p = fmin(nd->lam[i] - nd->mu * c[i], 0.0);
+    double f = nd->lam[i] - nd->mu * c[i];
+    double p = nd->eq ? f : fmin(f, 0.0);
     al += p * p - nd->lam[i] * nd->lam[i];
   }
   al = 0.5 / nd->mu * al;
@@ -290,24 +292,34 @@ static void nw_cost_jacobian(nw_node* nd, const double* x, const double* u, doub
   /* columns of cx^T / cu^T are zeroed where lambda_proj >= 0 (projection_jacobian2, constraints.h:429-436) */
   for (int a = 0; a < n; ++a) {
     double s = 0.0;
-    for (int i = 0; i < nd->c; ++i) s += ((nd->lp_[i] >= 0.0) ? 0.0 : nd->cx_[i * n + a]) * nd->lp_[i];
+    for (int i = 0; i < nd->c; ++i) s += ((!nd->eq && nd->lp_[i] >= 0.0) ? 0.0 : nd->cx_[i * n + a]) * nd->lp_[i];
     Jx[a] += -s;
   }
   for (int a = 0; a < m; ++a) {
     double s = 0.0;
-    for (int i = 0; i < nd->c; ++i) s += ((nd->lp_[i] >= 0.0) ? 0.0 : nd->B[i * m + a]) * nd->lp_[i];
+    for (int i = 0; i < nd->c; ++i) s += ((!nd->eq && nd->lp_[i] >= 0.0) ? 0.0 : nd->B[i * m + a]) * nd->lp_[i];
     Ju[a] += -s;
   }
   for (int a = 0; a < n; ++a)
     for (int b = 0; b < n; ++b) {
       double s = 0.0;
-      for (int i = 0; i < nd->c; ++i) s += (nd->mu * ((nd->lp_[i] >= 0.0) ? 0.0 : nd->cx_[i * n + a])) * nd->cx_[i * n + b];
+      if (nd->eq) {                               /* mu * (cx' cx), constraints.h:791-795 */
+        for (int i = 0; i < nd->c; ++i) s += nd->cx_[i * n + a] * nd->cx_[i * n + b];
+        s = nd->mu * s;
+      } else {
+        for (int i = 0; i < nd->c; ++i) s += (nd->mu * ((nd->lp_[i] >= 0.0) ? 0.0 : nd->cx_[i * n + a])) * nd->cx_[i * n + b];
+      }
       nd->dxdx[a * n + b] = s;
     }
   for (int a = 0; a < m; ++a)
     for (int b = 0; b < m; ++b) {
       double s = 0.0;
-      for (int i = 0; i < nd->c; ++i) s += (nd->mu * ((nd->lp_[i] >= 0.0) ? 0.0 : nd->B[i * m + a])) * nd->B[i * m + b];
+      if (nd->eq) {
+        for (int i = 0; i < nd->c; ++i) s += nd->B[i * m + a] * nd->B[i * m + b];
+        s = nd->mu * s;
+      } else {
+        for (int i = 0; i < nd->c; ++i) s += (nd->mu * ((nd->lp_[i] >= 0.0) ? 0.0 : nd->B[i * m + a])) * nd->B[i * m + b];
+      }
       nd->dudu[a * m + b] = s;
     }
 }
@@ -337,7 +349,10 @@ static double nw_max_violation(const nw_node* nd, const double* x, const double*
 static void nw_update_lambda(nw_node* nd, const double* x, const double* u) {
   double c[OR_NC];
   nw_constraints(nd, x, u, c);
-  for (int i = 0; i < nd->c; ++i) nd->lam[i] = fmin(nd->lam[i] - nd->mu * c[i], 0.0);
+  for (int i = 0; i < nd->c; ++i) {
+    double f = nd->lam[i] - nd->mu * c[i];
+    nd->lam[i] = nd->eq ? f : fmin(f, 0.0);     /* constraints.h:878-887 */
+  }
 }
 
 static void nw_node_init(nw_node* nd, const alilqr_problem* p, int t,
@@ -349,7 +364,8 @@ static void nw_node_init(nw_node* nd, const alilqr_problem* p, int t,
   nd->L = p->L; nd->dt = p->dt; nd->v = p->v; nd->k = p->k;
   nd->Q = Q + (size_t)tt * n * n;
   nd->R = R + (size_t)tt * m * m;
-  const int quad = (p->cons_kind == ALILQR_CONS_QUADRATIC);
+  const int quad = (p->cons_kind & ALILQR_CONS_QUADRATIC) ? 1 : 0;
+  nd->eq = (p->cons_kind & ALILQR_CONS_EQUALITY) ? 1 : 0;
   const double* b = cons + (size_t)tt * (c * n + c * m + c + (quad ? c * n * n : 0));
   memcpy(nd->Aown, b, sizeof(double) * c * n);
   memcpy(nd->Cown, b + c * n + c * m, sizeof(double) * c);

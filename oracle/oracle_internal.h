@@ -12,6 +12,7 @@
 /* One trajectory node of the Python generations: model + cost + AL state. */
 typedef struct or_node {
   int model, mode, n, m, c;
+  int eq;                              /* equality table (is_equality) */
   double L, dt, v, k;
   const double *Q, *R;                 /* n x n, m x m */
   double smin[OR_NX], smax[OR_NX], cmin[OR_NU], cmax[OR_NU];   /* legacy box */

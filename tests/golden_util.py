@@ -33,8 +33,10 @@ def problem_from_golden(g, idx=None):
             Cv = np.concatenate([-g["state_max"], g["state_min"], -g["control_max"], g["control_min"]])
         cons = capi.pack_linear(A, B, Cv)
         c = A.shape[0]
+    eq = ("eq" in g.files) and bool(g["eq"])
     desc = capi.make_problem(model, mode, H, x0.shape[0], float(g["L"]), float(g["dt"]),
-                             v=float(g["v"]), k=float(g["k"]), c=c)
+                             v=float(g["v"]), k=float(g["k"]), c=c,
+                             cons_kind=capi.CONS_EQUALITY if eq else capi.CONS_LINEAR)
     goals = np.ascontiguousarray(g["goals"], dtype=np.float64)
     return desc, x0, goals, np.ascontiguousarray(g["Q"], dtype=np.float64), \
         np.ascontiguousarray(g["R"], dtype=np.float64), cons

@@ -104,8 +104,11 @@ def test_fast_node_packs_its_constraint_object():
     nodes[0].state = np.array([31.0, 0, 0, 0, 10, 0])
     assert nodes[0].constraints[0] == 1.0                  # x - x_max
     eq = LinearConstraints(np.zeros((1, 6)), np.zeros((1, 2)), np.zeros(1), is_equality=True)
-    with pytest.raises(NotImplementedError):
-        FastBicycleNode(1.0, 0.1, 0.0, goals[0], np.eye(6), np.eye(2), eq).constraint_table()
+    eq_nodes = [FastBicycleNode(1.0, 0.1, 0.0, g_, np.eye(6), np.eye(2), copy.deepcopy(eq)) for g_ in goals]
+    d2 = FastILQR(eq_nodes)._describe(1, 20, 1e-8)[0]
+    assert d2.cons_kind == capi.CONS_EQUALITY and desc.cons_kind == capi.CONS_LINEAR
+    with pytest.raises(ValueError):
+        FastILQR([eq_nodes[0]] + nodes[1:])._describe(1, 20, 1e-8)
 
 
 def test_flat_module_names_of_the_reference_import(monkeypatch):

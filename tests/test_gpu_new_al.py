@@ -139,3 +139,45 @@ def test_new_al_node_kernel_matches_oracle(model, quad):
     for key in ("viol", "par_cost", "fxx"):
         assert gu.rel_err(aux[key][:, 0], raux[key][:, 0]) < 1e-11, key
     assert np.abs(aux["fxx"][:, 0]).max() > 0
+
+
+@pytest.mark.parametrize("model", ["new_bicycle", "lat_k"])
+def test_new_al_equality_table_matches_oracle(model):
+    """is_equality tables in the C++ generation (constraints.h:520-523, 673-676, 791-795, 880-882): node functions at
+    random points and full solves with a steering-law equality row u0 = -0.5 * delta."""
+    rng = np.random.default_rng(6)
+    n, m = (6, 2) if model == "new_bicycle" else (4, 1)
+    c = 2 if n == 6 else 1
+    A = np.zeros((c, n)); Bm = np.zeros((c, m)); Cv = np.zeros(c)
+    Bm[0, 0], A[0, 3] = 1.0, 0.5
+    if n == 6:
+        Bm[1, 1] = 1.0                                      # jerk = 0
+    cons = capi.pack_linear(A, Bm, Cv)
+    H, B = 30, 24
+    desc = capi.make_problem(model, "new_al", H, B, 3.0, 0.1, v=10.0, k=0.001, c=c, cons_kind=capi.CONS_EQUALITY)
+    desc.prm.max_outer, desc.prm.max_inner, desc.prm.viol_stop, desc.prm.viol_lambda = 30, 100, 1e-3, 5e-3
+    Q = np.diag([1e-1, 1e-1, 1.0, 1e-9, 1e-6, 1e-6][:n]) * 1e3
+    R = np.eye(m) * 1e2
+    goals = problems.s_curve_goals(10.0, 0.1, H, n == 6)
+    x0 = problems.full_start_states(B, 13) if n == 6 else problems.lat_start_states(B, 13)
+    ref = ol.solve_batch(desc, x0, goals, Q, R, cons)
+    o = to_np(batch.solve_batch(desc, x0, goals, Q, R, cons))
+    ok = stable_mask(desc, x0, goals, Q, R, cons, ref)
+    assert ok.mean() >= 0.5, ok.mean()
+    for i in np.nonzero(ok)[0]:
+        assert worst_err(o, ref, i) < TOL, (model, i, o["status"][i], ref["status"][i])
+    # equality multipliers take both signs
+    assert (ref["lam"] > 0).any() and (ref["lam"] < 0).any()
+    # node functions
+    N = 64
+    d1 = capi.make_problem(model, "new_al", 1, N, 3.0, 0.1, v=10.0, k=0.001, c=c, cons_kind=capi.CONS_EQUALITY)
+    X = rng.uniform(-1, 1, size=(N, n)) * ([30, 30, 2.5, 1.0, 4, 2][:n])
+    x = np.zeros((N, 2, n)); x[:, 0] = X
+    u = np.zeros((N, 2, m)); u[:, 0] = rng.uniform(-0.5, 0.5, size=(N, m))
+    lam = np.zeros((N, 2, c)); lam[:, 0] = rng.normal(size=(N, c))
+    MU = 10.0 ** rng.uniform(0, 3, size=N)
+    g2 = np.tile(rng.normal(size=n), (2, 1))
+    rl = ol.linearize_batch(d1, x, u, lam, MU, g2, Q, R, cons)
+    gl = to_np(batch.linearize_batch(d1, x, u, lam, MU, g2, Q, R, cons))
+    for key in ("l", "lx", "lu", "lxx", "luu"):
+        assert gu.rel_err(gl[key][:, 0], rl[key][:, 0]) < 1e-11, key

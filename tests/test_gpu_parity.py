@@ -51,7 +51,7 @@ def lanes(request, monkeypatch):
     return int(request.param)
 
 
-@pytest.mark.parametrize("name", ["lat_legacy", "dyn_legacy", "kin_legacy", "fast_box", "fast_linear"])
+@pytest.mark.parametrize("name", ["lat_legacy", "dyn_legacy", "kin_legacy", "fast_box", "fast_linear", "fast_equality"])
 def test_golden_sets(name, lanes):
     """GPU vs the reference's own vectors and vs the oracle, every lane-group width."""
     g = gu.load(name)
@@ -227,7 +227,8 @@ def test_solves_on_different_streams_overlap_and_match():
 
 
 @pytest.mark.parametrize("tag,model,mode", [("legacy_lat", "lat", "legacy"), ("legacy_dyn", "dyn", "legacy"),
-                                             ("fast_box", "dyn_mid", "fast"), ("fast_linear", "dyn_mid", "fast")])
+                                             ("fast_box", "dyn_mid", "fast"), ("fast_linear", "dyn_mid", "fast"),
+                                             ("fast_equality", "dyn_mid", "fast")])
 def test_node_aux_kernel_matches_reference_vectors(tag, model, mode):
     """alilqr_node_aux_batch: constraint values, one multiplier update and the violation term against the
     reference's golden points (and the oracle for the legacy violation term, which the goldens do not hold)."""
@@ -242,12 +243,16 @@ def test_node_aux_kernel_matches_reference_vectors(tag, model, mode):
     else:
         cons = capi.pack_linear(k[pre + "A"], k[pre + "B"], k[pre + "C"])
         desc = capi.make_problem(model, mode, 1, N, float(k[pre + "L"]), float(k[pre + "dt"]), k=float(k[pre + "k"]),
-                                 c=k[pre + "A"].shape[0])
+                                 c=k[pre + "A"].shape[0],
+                                 cons_kind=capi.CONS_EQUALITY if tag == "fast_equality" else capi.CONS_LINEAR)
     n, m = desc.n, desc.m
     goals = np.tile(k[pre + "goal"], (2, 1))
     x = np.zeros((N, 2, n)); x[:, 0] = X
     u = np.zeros((N, 2, m)); u[:, 0] = U
     lam = np.zeros((N, 2, desc.c)); lam[:, 0] = LAM
+    lin = to_np(batch.linearize_batch(desc, x, u, lam, MU, goals, k[pre + "Q"], k[pre + "R"], cons))
+    for key in ("f", "fx", "fu", "l", "lx", "lu", "lxx", "luu"):
+        assert gu.rel_err(lin[key][:, 0], k[pre + key]) < 1e-11, (tag, key)
     o = to_np(batch.node_aux_batch(desc, x, u, lam, MU, goals, k[pre + "Q"], k[pre + "R"], cons))
     assert gu.rel_err(o["cval"][:, 0], k[pre + "cons"]) < 1e-12
     assert gu.rel_err(o["lam_new"][:, 0], k[pre + "lam_new"]) < 1e-12

@@ -11,7 +11,7 @@ int main(int argc, char** argv) {
   alilqr_problem p;
   if (fread(&p, sizeof(p), 1, f) != 1) return 2;
   const size_t B = p.batch, H = p.horizon, n = p.n, m = p.m, c = p.c;
-  const size_t cw = (p.mode == ALILQR_MODE_LEGACY) ? 2 * (n + m) : c * (n + m + 1) + (p.cons_kind == ALILQR_CONS_QUADRATIC ? c * n * n : 0);
+  const size_t cw = (p.mode == ALILQR_MODE_LEGACY) ? 2 * (n + m) : c * (n + m + 1) + ((p.cons_kind & ALILQR_CONS_QUADRATIC) ? c * n * n : 0);
   auto x0 = rd(f, B * n), goals = rd(f, p.goal_batch * (H + 1) * n), Q = rd(f, p.table_nodes * n * n),
        R = rd(f, p.table_nodes * m * m), cons = rd(f, p.table_nodes * cw);
   // optional trailer: n_left, n_right, first_row, pad (int32) + rectangles

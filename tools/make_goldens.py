@@ -15,6 +15,7 @@ Sets written to tests/golden/:
   dyn_legacy.npz        ILQR + FullBicycleDynamicNode,   soft weights, H=100
   fast_box.npz          FastILQR + FastBicycleNode + BoxConstraint (test_fast_full.py setup)
   fast_linear.npz       FastILQR + FastBicycleNode(k=0) + LinearConstraints (box rows + half-planes)
+  fast_equality.npz     FastILQR + FastBicycleNode(k=0) + LinearConstraints(is_equality=True)
 """
 import argparse
 import contextlib
@@ -133,6 +134,18 @@ def fast_linear_problem(H=50):
     return p
 
 
+def fast_equality_problem(H=50):
+    """kinematic (k=0) fast node with an EQUALITY table (LinearConstraints(..., is_equality=True)):
+    jerk u1 = 0 and steering rate u0 = -0.5 * steering angle.  Both rows can be met at every node."""
+    p = full_problem("dyn_mid", H, mode="fast")
+    p.update(k=0.0)
+    A = np.zeros((2, 6)); Bm = np.zeros((2, 2)); C = np.zeros(2)
+    Bm[0, 1] = 1.0
+    Bm[1, 0] = 1.0; A[1, 3] = 0.5
+    p.update(A=A, B=Bm, C=C, eq=True)
+    return p
+
+
 # ----------------------------------------------------------------------------
 # traced solver runs
 # ----------------------------------------------------------------------------
@@ -188,7 +201,7 @@ def _build_nodes(ref, p):
                 nd = ref["Dyn"](L=p["L"], dt=p["dt"], k=p["k"], state_bounds=sb, control_bounds=cb, goal=g, Q=p["Q"], R=p["R"])
         else:
             if "A" in p:
-                cons = ref["Linear"](p["A"].copy(), p["B"].copy(), p["C"].copy())
+                cons = ref["Linear"](p["A"].copy(), p["B"].copy(), p["C"].copy(), is_equality=bool(p.get("eq", False)))
             else:
                 cons = ref["Box"](p["state_min"], p["state_max"], p["control_min"], p["control_max"])
             nd = ref["Fast"](p["L"], p["dt"], p["k"], g, p["Q"], p["R"], cons)
@@ -322,10 +335,14 @@ def node_kats():
         out[pre + "goal"] = np.array(nd.goal)
 
     # fast node + projection-form AL on box and general linear tables
-    for tag, p in (("fast_box", fast_box_problem(4)), ("fast_linear", fast_linear_problem(4))):
+    # (the equality table comes last so that the random draws of the earlier sets stay what they were)
+    for tag, p in (("fast_box", fast_box_problem(4)), ("fast_linear", fast_linear_problem(4)),
+                   ("fast_equality", fast_equality_problem(4))):
         n, m = 6, 2
         if tag == "fast_box":
             p["state_min"] = -np.array([3, 3, 1.0, 0.3, 12, 2.0]); p["state_max"] = np.array([3, 3, 1.0, 0.3, 12, 2.0])
+        elif tag == "fast_equality":
+            p["A"] = rng.uniform(-1, 1, size=(3, 6)); p["B"] = rng.uniform(-1, 1, size=(3, 2)); p["C"] = rng.uniform(-3, 3, size=3)
         else:
             p["A"] = rng.uniform(-1, 1, size=(6, 6)); p["B"] = rng.uniform(-1, 1, size=(6, 2)); p["C"] = rng.uniform(-3, 3, size=6)
         nodes = _build_nodes(ref, p)
@@ -333,7 +350,7 @@ def node_kats():
         c = nd.constraints_obj.constraint_dim
         X = rng.uniform(-1, 1, size=(N, n)) * np.array([5, 5, 4.0, 0.6, 3, 3.0]); X[:, 4] += 10.0
         U = rng.uniform(-1, 1, size=(N, m)) * np.array([0.3, 2.0])
-        LAM = np.minimum(0, rng.uniform(-1, 1, size=(N, c)))
+        LAM = rng.uniform(-1, 1, size=(N, c)) if p.get("eq") else np.minimum(0, rng.uniform(-1, 1, size=(N, c)))
         MU = rng.uniform(0.5, 20, size=N)
         rec = {k: [] for k in ("f", "fx", "fu", "l", "lx", "lu", "lxx", "luu", "cons", "lam_new", "viol")}
         for i in range(N):
@@ -385,6 +402,8 @@ def main():
         run_set("fast_box", fast_box_problem(50), x0, a.jobs)
     if want("fast_linear"):
         run_set("fast_linear", fast_linear_problem(50), full_x0(a.full, 5), a.jobs)
+    if want("fast_equality"):
+        run_set("fast_equality", fast_equality_problem(50), full_x0(a.full, 6), a.jobs)
 
 
 if __name__ == "__main__":
