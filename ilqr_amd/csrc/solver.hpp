@@ -906,6 +906,18 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   double mu = 1.0, old_cost = 0.0, viol = 0.0, dv_lin = 0.0;
   int outer = 0, inner = 0, n_inner = 0, n_trials = 0;
   bool outer_start = false;
+  // Each group is a small state machine that advances by at most one linearise + Riccati pass and one roll-out
+  // pass per trip of the wave loop: a group whose line search needs further passes (more rounds of trials, the
+  // ladder, a repeat) takes them in the following trips while the other groups of the wave, already on their
+  // next iteration, run their own linearisation and first round in the same instructions.
+  enum { PH_LIN = 0, PH_ROLL = 1 };
+  enum { ST_TRIALS = 0, ST_LADDER = 1, ST_REPLAY = 2, ST_DONE = 3 };
+  int phase = PH_LIN, stage = ST_DONE;
+  int np_ = 0;                // parity the candidates of the running line search are written to
+  double new_cost = 0.0, J_last = 0.0, replay_alpha = 0.0, bestJ = 0.0, bestA = 0.0;
+  bool keep_old = false, gate_skip = false, have = false;
+  int win_trial = -1, win_lane = -1, r0 = 0, replay_kind = 0;
+  size_t replay_ul = 0;
 
   // candidate trajectories.  G > 1: [group][parity][slot][element], a lane writes its roll-out as one contiguous
   // run and a node's (x, u) is one short run; G = 1: [parity][element][group * SS + slot], lane-minor, so the
@@ -1106,6 +1118,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         cur_slot = 0; cur_par = 0;
         outer = 0; inner = 0; n_inner = 0; n_trials = 0;
         outer_start = true;
+        phase = PH_LIN;
         __threadfence_block();
       }
     }
@@ -1114,6 +1127,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
     if (__ballot(p >= 0) == 0ull) break;
 
     if (p >= 0) {
+     if (phase == PH_LIN) {
       // ================= outer-iteration start: J under the current multipliers =================
       bool tables_changed = false;
       if (RECT) {
@@ -1170,7 +1184,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         if (outer_start) inner = 0;
         outer_start = false;
       }
-      const int np_ = 1 - cur_par;              // parity the candidates are written to
+      np_ = 1 - cur_par;
 
       PROF_MARK(1)
       // ================= P1: linearise + quadratise, parallel in time =================
@@ -1307,9 +1321,20 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         if (t == 0) sweep(0, LA, LB);
       }
       __threadfence_block();
+      // ---- a new line search starts
+      new_cost = old_cost;
+      keep_old = false;                          // NEW_AL: the trial costs were not finite, the trajectory stays
+      win_trial = -1; win_lane = -1;
+      J_last = 0.0;
+      gate_skip = NEWAL && (fabs(dv_lin) < a.prm.dv_gate);      // new_al_ilqr.h:1039
+      stage = gate_skip ? ST_DONE : ST_TRIALS;
+      r0 = 0;                                    // first trial of the current round, or first ladder column
+      replay_kind = 0; replay_alpha = 0.0; bestJ = 0.0; bestA = 0.0; replay_ul = 0; have = false;
+      phase = PH_ROLL;
+     }
 
       PROF_MARK(3)
-      // ================= P3: roll-outs, one line-search trial per lane =================
+      // ================= P3: roll-outs, one line-search trial per lane, one pass per trip =================
       struct RecRegs { double x[N], u[M], K[M][N], k[M], g[N], lam[CL]; };
       auto load_rec = [&](int t, RecRegs& R) {
         const double* r = rec(t);
@@ -1431,22 +1456,10 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         for (int q = 1; q < j && q < 64; ++q) al = al / 2.0;
         return al;
       };
-      double new_cost = old_cost;
-      bool keep_old = false;                     // NEW_AL: the trial costs were not finite, the trajectory stays
-      int win_trial = -1, win_lane = -1;
-      double J_last = 0.0;
-      const bool gate_skip = NEWAL && (fabs(dv_lin) < a.prm.dv_gate);      // new_al_ilqr.h:1039
       // The passes of the line search (rounds of trials, the C++ generation's ladder, the repeat of a winner
       // whose trajectory was not kept) go through ONE roll-out call: the groups of a wave that are in
       // different passes still execute it together, and the roll-out code exists once.
-      enum { ST_TRIALS = 0, ST_LADDER = 1, ST_REPLAY = 2, ST_DONE = 3 };
-      int stage = gate_skip ? ST_DONE : ST_TRIALS;
-      int r0 = 0;                                // first trial of the current round, or first ladder column
-      int replay_kind = 0;
-      double replay_alpha = 0.0, bestJ = 0.0, bestA = 0.0;
-      size_t replay_ul = 0;
-      bool have = false;
-      while (stage != ST_DONE) {
+      if (stage != ST_DONE) {
         bool valid = true;
         int kind = 0, sslot = -1;
         double alpha = 1.0;
@@ -1559,10 +1572,11 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
           stage = ST_DONE;
         }
       }
+      PROF_MARK(4)
+     if (stage == ST_DONE) {
       if (win_trial >= 0) cur_par = np_;
       __threadfence_block();
 
-      PROF_MARK(4)
       // ================= P4: inner / outer bookkeeping (ilqr.py:158-174) =================
 #ifdef ALILQR_EMU_TRACE
       if (gl == 0 && p == 0) printf("it %d outer %d old %.17g new %.17g win %d slot %d dv %.6g gate %d keep %d trials %d\n", n_inner, outer, old_cost, new_cost, win_trial, cur_slot, dv_lin, (int)gate_skip, (int)keep_old, n_trials);
@@ -1646,6 +1660,8 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
         }
         p = -1;
       }
+      phase = PH_LIN;
+     }
       PROF_MARK(5)
     }
   }
