@@ -126,7 +126,7 @@ def alloc_outputs_numpy(B, H, n, m, c, extras=True):
 # the HIP library
 # ---------------------------------------------------------------------------
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libalilqr_hip.so")
+LIB_PATH = os.environ.get("ALILQR_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libalilqr_hip.so")
 
 EXPORTS = ("alilqr_abi_version", "alilqr_last_error", "alilqr_device_count", "alilqr_default_params",
            "alilqr_workspace_bytes", "alilqr_solve_batch", "alilqr_solve_batch_multistart", "alilqr_solve_batch_ex",

@@ -170,6 +170,18 @@ Plan make_plan(const alilqr_problem* p, const Dims& d, bool rect = false) {
 template <int MODEL, int MODE>
 int32_t launch_g(const alilqr::KArgs& ka, int G, int waves, hipStream_t st) {
   dim3 grid(waves), block(64);
+  if constexpr (MODE == ALILQR_MODE_LEGACY) {
+    // 32-lane LEGACY kernels keep their linearisation records in LDS when two groups' worth of them fit eight
+    // (4-state, 2 waves per SIMD) or four (6-state, 1 wave per SIMD) times into the 160 KB of a CU
+    using MDx = alilqr::Model<MODEL>;
+    const size_t lds = (size_t)2 * (ka.H + 1) * alilqr::NodeRec<MDx, MODE>::E * sizeof(double);
+    const size_t room = (MDx::N == 4) ? 160 * 1024 / 8 : 160 * 1024 / 4;
+    if (G == 32 && lds <= room && !std::getenv("ALILQR_NO_LDS")) {
+      hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 32, true>), grid, block, lds, st, ka);
+      HIP_TRY(hipGetLastError());
+      return ALILQR_OK;
+    }
+  }
   switch (G) {
     case 1: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 1>), grid, block, 0, st, ka); break;
     case 4: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 4>), grid, block, 0, st, ka); break;
@@ -431,6 +443,13 @@ int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
   ka.prof = (unsigned long long*)(base + pl.counter + 128);   // zeroed with the counter; read by profiling builds
   const int waves = pl.NG * pl.G / 64;
 
+#ifdef ALILQR_HEADLINE_ONLY
+  /* development builds (-DALILQR_HEADLINE_ONLY=<model id>): only that LEGACY kernel family is instantiated
+     (seconds instead of minutes to compile) */
+  if (p->mode == ALILQR_MODE_LEGACY && p->model == ALILQR_HEADLINE_ONLY) return launch_g<ALILQR_HEADLINE_ONLY, ALILQR_MODE_LEGACY>(ka, pl.G, waves, st);
+  set_err("development build: one LEGACY kernel family only");
+  return ALILQR_E_ARG;
+#else
   if (p->mode == ALILQR_MODE_LEGACY) {
     switch (p->model) {
       case ALILQR_MODEL_LAT: return launch_g<ALILQR_MODEL_LAT, ALILQR_MODE_LEGACY>(ka, pl.G, waves, st);
@@ -461,6 +480,7 @@ int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
   }
   set_err("unsupported model / mode combination");
   return ALILQR_E_ARG;
+#endif
 }
 
 static int32_t node_eval(const alilqr_problem* p,

@@ -20,7 +20,8 @@
 //
 // Data layout in HBM (fp64).
 //   blk  one block per group: H+1 step records  x_t | u_t | K_t | k_t | goal_t | lambda_t
-//        followed by H+1 linearisation records  f_x, f_u entries | l_x | l_u | l_xx | l_uu.
+//        followed by H+1 linearisation records  f_x, f_u entries | l_x | l_u | l_xx | l_uu
+//        (the linearisation records live in LDS instead where they fit at full occupancy).
 //        G > 1: the block is contiguous (problem-major), so a sequential sweep reads one
 //        short run of doubles per step from one base address; G = 1: element-major /
 //        group-minor, so the 64 problems of a wave read one contiguous run per element.
@@ -817,6 +818,9 @@ __host__ __device__ inline size_t block_doubles(int H, int C) {
   return (size_t)(H + 1) * (RS + NodeRec<MD, MODE>::E);
 }
 
+#ifndef ALILQR_TRIP_N6
+#define ALILQR_TRIP_N6 0   // per-trip passes for the 6-state kernels too (measured slower: their register allocation suffers)
+#endif
 #ifndef ALILQR_MINW_N4
 #define ALILQR_MINW_N4 2   // waves per SIMD the 4-state kernels are compiled for (256 registers per lane)
 #endif
@@ -838,7 +842,7 @@ struct FxxOf<MD, true> {
   }
 };
 
-template <int MODEL, int MODE, int G>
+template <int MODEL, int MODE, int G, bool LDSLIN = false>
 __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) void solve_kernel(KArgs a) {
   using MD = Model<MODEL>;
   using OPS = NodeOps<MODEL, MODE>;
@@ -850,6 +854,10 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   constexpr bool NEWAL = is_new_al(MODE);
   constexpr bool QUAD = is_quad(MODE);
   constexpr bool RECT = is_rect(MODE);
+  // One roll-out pass per trip of the wave loop where a wave carries more than two groups (their line searches
+  // need different numbers of passes); with two groups per wave the passes of a line search run back to back,
+  // which also keeps the register allocation of the 6-state kernels tight.
+  constexpr bool TRIP = (G < 32) && (N == 4 || ALILQR_TRIP_N6);
   constexpr bool PM = (G > 1);                         // block layout: problem-major (contiguous) or element-major
   constexpr int CL = LEGACY ? 2 * (N + M) : 1;         // multipliers held in registers (LEGACY only)
   constexpr int SS = TrjSlots<MODE>::SS;               // trajectory slots kept per problem and parity
@@ -867,7 +875,11 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   const int RS = record_doubles<MD, MODE>(C);
   const size_t ES = PM ? (size_t)1 : NG;               // element stride inside the block
   double* const blk = a.blk + (PM ? gid * block_doubles<MD, MODE>(H, C) : gid);
-  double* const linb = blk + (size_t)(H + 1) * RS * ES;
+  // Linearisation records of the group: in LDS when the host found room for them at full occupancy (the
+  // sequential Riccati sweep then reads them with LDS latency and they cause no memory traffic), else in the
+  // group's block in HBM.
+  extern __shared__ double lds_pool[];
+  double* const linb = LDSLIN ? lds_pool + (size_t)(lane / G) * (H + 1) * NR::E : blk + (size_t)(H + 1) * RS * ES;
 
   double* const trj = a.trj;
   const int cw = LEGACY ? (2 * N + 2 * M) : C * (N + M + 1) + (QUAD ? C * N * N : 0);   // doubles per constraint table
@@ -1334,7 +1346,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
      }
 
       PROF_MARK(3)
-      // ================= P3: roll-outs, one line-search trial per lane, one pass per trip =================
+      // ================= P3: roll-outs, one line-search trial per lane =================
       struct RecRegs { double x[N], u[M], K[M][N], k[M], g[N], lam[CL]; };
       auto load_rec = [&](int t, RecRegs& R) {
         const double* r = rec(t);
@@ -1459,7 +1471,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
       // The passes of the line search (rounds of trials, the C++ generation's ladder, the repeat of a winner
       // whose trajectory was not kept) go through ONE roll-out call: the groups of a wave that are in
       // different passes still execute it together, and the roll-out code exists once.
-      if (stage != ST_DONE) {
+      while (stage != ST_DONE) {
         bool valid = true;
         int kind = 0, sslot = -1;
         double alpha = 1.0;
@@ -1571,6 +1583,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
           if (NEWAL && win_trial == 0) { new_cost = J; ++n_trials; }   // the ladder winner is re-run with the sequential arithmetic
           stage = ST_DONE;
         }
+        if (TRIP) break;                         // further passes in the following trips
       }
       PROF_MARK(4)
      if (stage == ST_DONE) {
@@ -1578,9 +1591,6 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
       __threadfence_block();
 
       // ================= P4: inner / outer bookkeeping (ilqr.py:158-174) =================
-#ifdef ALILQR_EMU_TRACE
-      if (gl == 0 && p == 0) printf("it %d outer %d old %.17g new %.17g win %d slot %d dv %.6g gate %d keep %d trials %d\n", n_inner, outer, old_cost, new_cost, win_trial, cur_slot, dv_lin, (int)gate_skip, (int)keep_old, n_trials);
-#endif
       ++n_inner; ++inner;
       // inner stop rule: |dJ| < tol (ilqr.py:162) ; 0 <= J_old - J_new < tol (new_al_ilqr.h:1118)
       const bool brk = NEWAL ? ((old_cost - new_cost < a.prm.inner_tol) && (old_cost - new_cost >= 0))

@@ -260,3 +260,17 @@ def test_node_aux_kernel_matches_reference_vectors(tag, model, mode):
     assert gu.rel_err(o["viol"][:, 0], ref["viol"][:, 0]) < 1e-12
     if mode == "fast":
         assert gu.rel_err(o["viol"][:, 0], k[pre + "viol"]) < 1e-12
+
+
+def test_lds_resident_linearisation_records_do_not_change_bits(monkeypatch):
+    """The 32-lane LEGACY kernels keep their linearisation records in LDS where they fit; ALILQR_NO_LDS=1 forces
+    the HBM path.  Same arithmetic, same bits."""
+    outs = []
+    for prob in (problems.lat_legacy(96, 50, seed=31), problems.full_legacy("dyn", 48, 60, 32)):
+        monkeypatch.delenv("ALILQR_NO_LDS", raising=False)
+        a = to_np(batch.solve_batch(*prob))
+        monkeypatch.setenv("ALILQR_NO_LDS", "1")
+        b = to_np(batch.solve_batch(*prob))
+        monkeypatch.delenv("ALILQR_NO_LDS", raising=False)
+        for k in ("x", "u", "cost", "status", "lam"):
+            assert np.array_equal(a[k], b[k], equal_nan=True), k

@@ -1,6 +1,7 @@
 // Runs one problem file (written by tools/host_emu/dump_problem.py) through the kernel compiled for the host.
 #include "../../ilqr_amd/csrc/alilqr_api.hip"
 #include <vector>
+namespace alilqr { double lds_pool[20480]; }   // 160 KB: the LDS of one CU
 
 static std::vector<double> rd(FILE* f, size_t n) { std::vector<double> v(n); if (n && fread(v.data(), 8, n, f) != n) { perror("read"); exit(2); } return v; }
 

@@ -15,6 +15,9 @@
 #define __global__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#define __shared__
+// dynamic LDS of the emulated wave (block-scope `extern __shared__` declarations inside namespace alilqr bind here)
+namespace alilqr { extern double lds_pool[]; }
 
 struct emu_dim3 { unsigned x = 1, y = 1, z = 1; emu_dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 typedef emu_dim3 dim3;

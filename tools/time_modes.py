@@ -12,6 +12,8 @@ def main():
     sets = {
         "legacy lat H50": problems.lat_legacy(B),
         "legacy dyn H100": problems.full_legacy("dyn", B, 100, 2),
+        "legacy dyn H60": problems.full_legacy("dyn", B, 60, 2),
+        "legacy kin H50": problems.full_legacy("kin", B, 50, 1),
         "fast box H50": problems.fast_box(B),
         "fast box+linear H100": problems.fast_box_linear(B),
         "new_al box6 H50": problems.new_al_box(B),
