@@ -11,7 +11,18 @@
 #include <mutex>
 
 #include "../../include/alilqr.h"
-#include "solver.hpp"
+#include "launch.hpp"
+
+// the kernel families: defined here in single-translation-unit builds, in their own objects otherwise
+namespace alilqr {
+#ifdef ALILQR_SINGLE_TU
+#define X(m, k) ALILQR_DEFINE_FAMILY(m, k)
+#else
+#define X(m, k) ALILQR_DECLARE_FAMILY(m, k)
+#endif
+#include "families.inc"
+#undef X
+}  // namespace alilqr
 
 namespace {
 
@@ -165,33 +176,6 @@ Plan make_plan(const alilqr_problem* p, const Dims& d, bool rect = false) {
   pl.blk = off; off = up(off + sizeof(double) * block_doubles_for(p, rect) * (size_t)pl.NG);
   pl.total = off;
   return pl;
-}
-
-template <int MODEL, int MODE>
-int32_t launch_g(const alilqr::KArgs& ka, int G, int waves, hipStream_t st) {
-  dim3 grid(waves), block(64);
-  if constexpr (MODE == ALILQR_MODE_LEGACY) {
-    // 32-lane LEGACY kernels keep their linearisation records in LDS when two groups' worth of them fit eight
-    // (4-state, 2 waves per SIMD) or four (6-state, 1 wave per SIMD) times into the 160 KB of a CU
-    using MDx = alilqr::Model<MODEL>;
-    const size_t lds = (size_t)2 * (ka.H + 1) * alilqr::NodeRec<MDx, MODE>::E * sizeof(double);
-    const size_t room = (MDx::N == 4) ? 160 * 1024 / 8 : 160 * 1024 / 4;
-    if (G == 32 && lds <= room && !std::getenv("ALILQR_NO_LDS")) {
-      hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 32, true>), grid, block, lds, st, ka);
-      HIP_TRY(hipGetLastError());
-      return ALILQR_OK;
-    }
-  }
-  switch (G) {
-    case 1: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 1>), grid, block, 0, st, ka); break;
-    case 4: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 4>), grid, block, 0, st, ka); break;
-    case 8: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 8>), grid, block, 0, st, ka); break;
-    case 16: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 16>), grid, block, 0, st, ka); break;
-    case 32: hipLaunchKernelGGL((alilqr::solve_kernel<MODEL, MODE, 32>), grid, block, 0, st, ka); break;
-    default: set_err("bad lane-group width"); return ALILQR_E_ARG;
-  }
-  HIP_TRY(hipGetLastError());
-  return ALILQR_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -443,44 +427,18 @@ int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
   ka.prof = (unsigned long long*)(base + pl.counter + 128);   // zeroed with the counter; read by profiling builds
   const int waves = pl.NG * pl.G / 64;
 
-#ifdef ALILQR_HEADLINE_ONLY
-  /* development builds (-DALILQR_HEADLINE_ONLY=<model id>): only that LEGACY kernel family is instantiated
-     (seconds instead of minutes to compile) */
-  if (p->mode == ALILQR_MODE_LEGACY && p->model == ALILQR_HEADLINE_ONLY) return launch_g<ALILQR_HEADLINE_ONLY, ALILQR_MODE_LEGACY>(ka, pl.G, waves, st);
-  set_err("development build: one LEGACY kernel family only");
+  // kernel family = model x kernel mode (families.inc)
+  const int kmode = (p->mode == ALILQR_MODE_NEW_AL) ? new_al_variant(p, rect) : p->mode;
+  const int no_lds = std::getenv("ALILQR_NO_LDS") ? 1 : 0;
+  int lr = -1;
+#define X(m, k) if (p->model == (m) && kmode == (k)) lr = alilqr::ALILQR_FAMILY_NAME(m, k)(ka, pl.G, waves, st, no_lds);
+#include "families.inc"
+#undef X
+  if (lr == alilqr::LAUNCH_OK) return ALILQR_OK;
+  if (lr == alilqr::LAUNCH_BAD_WIDTH) { set_err("bad lane-group width"); return ALILQR_E_ARG; }
+  if (lr == alilqr::LAUNCH_FAILED) { set_err("kernel launch failed"); return ALILQR_E_HIP; }
+  set_err("unsupported model / mode combination (or a development build without this kernel family)");
   return ALILQR_E_ARG;
-#else
-  if (p->mode == ALILQR_MODE_LEGACY) {
-    switch (p->model) {
-      case ALILQR_MODEL_LAT: return launch_g<ALILQR_MODEL_LAT, ALILQR_MODE_LEGACY>(ka, pl.G, waves, st);
-      case ALILQR_MODEL_KIN: return launch_g<ALILQR_MODEL_KIN, ALILQR_MODE_LEGACY>(ka, pl.G, waves, st);
-      case ALILQR_MODEL_DYN: return launch_g<ALILQR_MODEL_DYN, ALILQR_MODE_LEGACY>(ka, pl.G, waves, st);
-      default: break;
-    }
-  } else if (p->mode == ALILQR_MODE_FAST) {
-    if (p->model == ALILQR_MODEL_DYN_MID) return launch_g<ALILQR_MODEL_DYN_MID, ALILQR_MODE_FAST>(ka, pl.G, waves, st);
-  } else if (p->mode == ALILQR_MODE_NEW_AL) {
-    const int variant = new_al_variant(p, rect);
-    if (p->model == ALILQR_MODEL_LAT_K) {
-      switch (variant) {
-        case alilqr::kModeNewAlQuad: return launch_g<ALILQR_MODEL_LAT_K, alilqr::kModeNewAlQuad>(ka, pl.G, waves, st);
-        case alilqr::kModeNewAlRect: return launch_g<ALILQR_MODEL_LAT_K, alilqr::kModeNewAlRect>(ka, pl.G, waves, st);
-        case alilqr::kModeNewAlQuadRect: return launch_g<ALILQR_MODEL_LAT_K, alilqr::kModeNewAlQuadRect>(ka, pl.G, waves, st);
-        default: return launch_g<ALILQR_MODEL_LAT_K, ALILQR_MODE_NEW_AL>(ka, pl.G, waves, st);
-      }
-    }
-    if (p->model == ALILQR_MODEL_NEW_BICYCLE) {
-      switch (variant) {
-        case alilqr::kModeNewAlQuad: return launch_g<ALILQR_MODEL_NEW_BICYCLE, alilqr::kModeNewAlQuad>(ka, pl.G, waves, st);
-        case alilqr::kModeNewAlRect: return launch_g<ALILQR_MODEL_NEW_BICYCLE, alilqr::kModeNewAlRect>(ka, pl.G, waves, st);
-        case alilqr::kModeNewAlQuadRect: return launch_g<ALILQR_MODEL_NEW_BICYCLE, alilqr::kModeNewAlQuadRect>(ka, pl.G, waves, st);
-        default: return launch_g<ALILQR_MODEL_NEW_BICYCLE, ALILQR_MODE_NEW_AL>(ka, pl.G, waves, st);
-      }
-    }
-  }
-  set_err("unsupported model / mode combination");
-  return ALILQR_E_ARG;
-#endif
 }
 
 static int32_t node_eval(const alilqr_problem* p,

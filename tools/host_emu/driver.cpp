@@ -1,4 +1,5 @@
 // Runs one problem file (written by tools/host_emu/dump_problem.py) through the kernel compiled for the host.
+#define ALILQR_SINGLE_TU 1
 #include "../../ilqr_amd/csrc/alilqr_api.hip"
 #include <vector>
 namespace alilqr { double lds_pool[20480]; }   // 160 KB: the LDS of one CU

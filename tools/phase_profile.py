@@ -13,9 +13,9 @@ import numpy as np
 def build():
     out = os.path.join(ROOT, "ilqr_amd", "csrc", "libalilqr_hip_prof.so")
     src = os.path.join(ROOT, "ilqr_amd", "csrc", "alilqr_api.hip")
-    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(os.path.join(ROOT, "ilqr_amd", "csrc", f)) for f in ("alilqr_api.hip", "solver.hpp", "models.hpp")):
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(os.path.join(ROOT, "ilqr_amd", "csrc", f)) for f in ("alilqr_api.hip", "solver.hpp", "models.hpp", "launch.hpp", "families.inc")):
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                        "-DALILQR_PROF", "-o", out, src], check=True)
+                        "-DALILQR_PROF", "-DALILQR_SINGLE_TU", "-DALILQR_HEADLINE_ONLY=0", "-o", out, src], check=True)
     return out
 
 def main():
