@@ -57,16 +57,16 @@ def cpu_baseline(sample, seconds_hint=20.0):
     oracle_lib.solve_batch(desc, x0, goals, Q, R, cons, threads=threads, extras=False)
     dt = time.perf_counter() - t0
     return dict(value=sample / dt, unit="solves/s", cores=threads, kind="port",
-                sample=f"first {sample} problems of the same 4096-problem batch, OpenMP over problems, {dt:.2f} s wall")
+                sample=f"the first {sample} problems of the 4096-problem batch of rank 0, OpenMP over problems, {dt:.2f} s wall")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (HIP streams used in turn)")
     args = ap.parse_args()
@@ -143,14 +143,18 @@ def main():
     hit_cap = float(np.mean((status[:, 2] & capi.FLAG_OUTER_CAP) != 0))
 
     if rank == 0:
-        traffic = None
+        # counters of the same launch, collected in separate rocprofv3 --pmc passes (tools/profile_round.sh)
+        traffic = valu_active = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as fh:
-                    traffic = json.load(fh).get("hbm_bytes_per_launch")
-            except (OSError, ValueError):
-                traffic = None
+                    counters = json.load(fh)
+                traffic = counters.get("hbm_bytes_per_launch")
+                if counters.get("SQ_WAVE_CYCLES"):
+                    valu_active = counters["SQ_ACTIVE_INST_VALU"] / counters["SQ_WAVE_CYCLES"]
+            except (OSError, ValueError, KeyError):
+                traffic = valu_active = None
         line = {
             "metric": "converged AL-iLQR solves/sec (H=50, batch N)",
             "value": world * B * args.steps / dt,
@@ -169,10 +173,14 @@ def main():
                        "batch_per_gpu": B, "horizon": H, "mode": "legacy", "model": "lat",
                        "lanes_per_problem": os.environ.get("ALILQR_LANES", "auto"),
                        "batches_in_flight": depth, "lone_launch_ms": lone_ms,
+                       # latency of one iLQR iteration (linearise, backward sweep, line search) of one problem with the
+                       # whole batch resident: a lone launch lasts as long as its longest solve
+                       "per_iter_latency_us": lone_ms * 1e3 / max(1, int(status[:, 0].max())),
                        "mean_inner_iters": float(status[:, 0].mean()), "mean_rollouts": float(status[:, 3].mean()),
                        "frac_outer_cap": hit_cap, "frac_nonfinite": float(np.mean(~np.isfinite(cost)))},
             "roofline": {"bound": "valu_fp64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
+                         "valu_active_share_of_wave_cycles": valu_active,
                          "kernel": "alilqr::solve_kernel", "kernel_ms": kernel_ms,
                          "achieved_job": tf_job, "frac_job": tf_job / FP64_VALU_PEAK_TFLOPS,
                          "algorithmic_flops_per_launch": flops,

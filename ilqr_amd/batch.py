@@ -44,8 +44,8 @@ def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=
     ``u_offset`` [B,H,m] (optional) perturbs the controls of the initial guess: B starts of one scenario.
     ``left_obs`` / ``right_obs`` (optional, NEW_AL): lists of 2x4 rectangle vertex matrices whose y-bounds are
     written into the nodes' constraint tables while the solve runs; ``first_row`` is the row index the nodes start from.
-    Returns a dict of device tensors: x [B,H+1,n], u [B,H,m], cost [B] and, with
-    ``extras``, node_x, node_u, x_init, u_init, viol, lam, mu, status.
+    Returns a dict of device tensors: x [B,H+1,n], u [B,H,m], cost [B], status [B,4] and, with
+    ``extras``, node_x, node_u, x_init, u_init, viol, lam, mu.
     """
     torch = _torch()
     lib = capi.load_library()
@@ -71,12 +71,12 @@ def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=
     ex = capi.Extras(None if uo_d is None else uo_d.data_ptr(), None if lo_d is None else lo_d.data_ptr(),
                      None if ro_d is None else ro_d.data_ptr(), len(lo), len(ro), int(first_row), 0)
     f64 = dict(dtype=torch.float64, device=dev)
-    out = dict(x=torch.empty((B, H + 1, n), **f64), u=torch.empty((B, H, m), **f64), cost=torch.empty((B,), **f64))
+    out = dict(x=torch.empty((B, H + 1, n), **f64), u=torch.empty((B, H, m), **f64), cost=torch.empty((B,), **f64),
+               status=torch.zeros((B, capi.STATUS_WORDS), dtype=torch.int32, device=dev))
     if extras:
         out.update(node_x=torch.empty((B, H + 1, n), **f64), node_u=torch.empty((B, H, m), **f64),
                    x_init=torch.empty((B, H + 1, n), **f64), u_init=torch.empty((B, H, m), **f64),
-                   viol=torch.empty((B,), **f64), lam=torch.empty((B, H + 1, c), **f64), mu=torch.empty((B,), **f64),
-                   status=torch.zeros((B, capi.STATUS_WORDS), dtype=torch.int32, device=dev))
+                   viol=torch.empty((B,), **f64), lam=torch.empty((B, H + 1, c), **f64), mu=torch.empty((B,), **f64))
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = lib.alilqr_solve_batch_ex(C.byref(desc), _ptr(x0_d), _ptr(goals_d), _ptr(Q_d), _ptr(R_d), _ptr(cons_d),
