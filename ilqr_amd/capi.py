@@ -11,9 +11,9 @@ import numpy as np
 ABI_VERSION = 2
 STATUS_WORDS = 4
 
-MODELS = {"lat": 0, "kin": 1, "dyn": 2, "dyn_mid": 3, "lat_k": 4, "new_bicycle": 5}
+MODELS = {"lat": 0, "kin": 1, "dyn": 2, "dyn_mid": 3, "lat_k": 4, "new_bicycle": 5, "lon": 6, "lat_interior": 7}
 MODES = {"legacy": 0, "fast": 1, "new_al": 2}
-MODEL_DIMS = {0: (4, 1), 1: (6, 2), 2: (6, 2), 3: (6, 2), 4: (4, 1), 5: (6, 2)}
+MODEL_DIMS = {0: (4, 1), 1: (6, 2), 2: (6, 2), 3: (6, 2), 4: (4, 1), 5: (6, 2), 6: (3, 1), 7: (4, 1)}
 DV_GATE = 0.20000000298023224   # the float literal 0.2F of new_al_ilqr.h:1039, as a double
 
 FLAG_VIOL_OK = 1
@@ -81,7 +81,7 @@ def make_problem(model, mode, horizon, batch, L, dt, v=0.0, k=0.0, c=None,
     if c is None:
         if mode_id != MODES["legacy"]:
             raise ValueError("constraint row count c is required for the fast / new_al generations")
-        c = 2 * (n + m)
+        c = 2 * n if model_id == MODELS["lat_interior"] else 2 * (n + m)   # the interior node bounds states only
     prm = params if params is not None else default_params(mode_id)
     return Problem(ABI_VERSION, model_id, mode_id, int(horizon), n, m, int(c), int(batch),
                    int(goal_batch), int(table_nodes), int(cons_kind), 0, float(L), float(dt), float(v), float(k), prm)

@@ -62,7 +62,9 @@ struct Dims {
 bool model_dims(int model, Dims* d) {
   using namespace alilqr;
   switch (model) {
+    case ALILQR_MODEL_LON: *d = {3, 1, Model<ALILQR_MODEL_LON>::NA, Model<ALILQR_MODEL_LON>::NB, LinLayout<Model<ALILQR_MODEL_LON>>::E}; return true;
     case ALILQR_MODEL_LAT:
+    case ALILQR_MODEL_LAT_INTERIOR:
     case ALILQR_MODEL_LAT_K: *d = {4, 1, Model<ALILQR_MODEL_LAT>::NA, Model<ALILQR_MODEL_LAT>::NB, LinLayout<Model<ALILQR_MODEL_LAT>>::E}; return true;
     case ALILQR_MODEL_KIN:
     case ALILQR_MODEL_DYN:
@@ -88,10 +90,13 @@ int32_t check_problem(const alilqr_problem* p, Dims* d) {
     set_err("quadratic constraint tables are defined for NEW_AL"); return ALILQR_E_ARG;
   }
   if (p->mode == ALILQR_MODE_LEGACY) {
-    if (p->c != 2 * (p->n + p->m)) { set_err("LEGACY needs c = 2(n+m)"); return ALILQR_E_ARG; }
-    if (p->model != ALILQR_MODEL_LAT && p->model != ALILQR_MODEL_KIN && p->model != ALILQR_MODEL_DYN) {
-      set_err("LEGACY is defined for LAT, KIN, DYN"); return ALILQR_E_ARG;
+    if (p->model != ALILQR_MODEL_LAT && p->model != ALILQR_MODEL_KIN && p->model != ALILQR_MODEL_DYN &&
+        p->model != ALILQR_MODEL_LON && p->model != ALILQR_MODEL_LAT_INTERIOR) {
+      set_err("LEGACY is defined for LAT, KIN, DYN, LON, LAT_INTERIOR"); return ALILQR_E_ARG;
     }
+    if (p->model == ALILQR_MODEL_LAT_INTERIOR) {
+      if (p->c != 2 * p->n) { set_err("LAT_INTERIOR bounds states only: c = 2n"); return ALILQR_E_ARG; }
+    } else if (p->c != 2 * (p->n + p->m)) { set_err("LEGACY needs c = 2(n+m)"); return ALILQR_E_ARG; }
   } else if (p->mode == ALILQR_MODE_FAST) {
     if (p->c < 1 || p->c > 64) { set_err("FAST needs 1 <= c <= 64"); return ALILQR_E_ARG; }
     if (p->model != ALILQR_MODEL_DYN_MID) { set_err("FAST is defined for DYN_MID"); return ALILQR_E_ARG; }
@@ -144,6 +149,8 @@ size_t block_doubles_for(const alilqr_problem* p, bool rect) {
   const int H = p->horizon, C = p->c;
   if (p->mode == ALILQR_MODE_LEGACY) {
     if (p->model == ALILQR_MODEL_LAT) return block_doubles<Model<ALILQR_MODEL_LAT>, ALILQR_MODE_LEGACY>(H, C);
+    if (p->model == ALILQR_MODEL_LON) return block_doubles<Model<ALILQR_MODEL_LON>, ALILQR_MODE_LEGACY>(H, C);
+    if (p->model == ALILQR_MODEL_LAT_INTERIOR) return block_doubles<Model<ALILQR_MODEL_LAT_INTERIOR>, ALILQR_MODE_LEGACY>(H, C);
     return block_doubles<Model<ALILQR_MODEL_KIN>, ALILQR_MODE_LEGACY>(H, C);
   }
   if (p->mode == ALILQR_MODE_NEW_AL) {
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(256) void linearize_kernel(LArgs a) {
   MD::step(a.mc, x, u, xn);
   MD::jac(a.mc, x, u, ac, bc);
   expand_jac<MD>(a.mc, ac, bc, S, Bm);
-  if (!is_new_al(MODE)) {
+  if constexpr (!is_new_al(MODE) && MD::WRAPS) {
     // the Python node keeps its state angle-wrapped from its first cost call on
     x[2] = wrap_py(x[2]);
     x[3] = wrap_py(x[3]);
@@ -475,6 +482,8 @@ static int32_t node_eval(const alilqr_problem* p,
       case ALILQR_MODEL_LAT: hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_LAT, ALILQR_MODE_LEGACY>), grid, block, 0, st, a); break;
       case ALILQR_MODEL_KIN: hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_KIN, ALILQR_MODE_LEGACY>), grid, block, 0, st, a); break;
       case ALILQR_MODEL_DYN: hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_DYN, ALILQR_MODE_LEGACY>), grid, block, 0, st, a); break;
+      case ALILQR_MODEL_LON: hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_LON, ALILQR_MODE_LEGACY>), grid, block, 0, st, a); break;
+      case ALILQR_MODEL_LAT_INTERIOR: hipLaunchKernelGGL((linearize_kernel<ALILQR_MODEL_LAT_INTERIOR, ALILQR_MODE_LEGACY>), grid, block, 0, st, a); break;
       default: set_err("unsupported model / mode combination"); return ALILQR_E_ARG;
     }
   } else if (p->mode == ALILQR_MODE_NEW_AL) {

@@ -18,7 +18,7 @@ inline int launch_family(const KArgs& ka, int G, int waves, hipStream_t st, int 
     // (4-state, 2 waves per SIMD) or four (6-state, 1 wave per SIMD) times into the 160 KB of a CU
     using MDx = Model<MODEL>;
     const size_t lds = (size_t)2 * (ka.H + 1) * NodeRec<MDx, MODE>::E * sizeof(double);
-    const size_t room = (MDx::N == 4) ? 160 * 1024 / 8 : 160 * 1024 / 4;
+    const size_t room = (MDx::N <= 4) ? 160 * 1024 / 8 : 160 * 1024 / 4;
     if (G == 32 && lds <= room && !no_lds) {
       hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32, true>), grid, block, lds, st, ka);
       return hipGetLastError() == hipSuccess ? LAUNCH_OK : LAUNCH_FAILED;

@@ -57,9 +57,12 @@ template <int MODEL>
 struct Model;
 
 // ---- 4 states / 1 control ---------------------------------------------------
+// Traits read by the solver: WRAPS — states 2 and 3 are angles kept in [-pi, pi); CTRL_ROWS — the LEGACY box holds
+// control rows (c = 2(n+m)) or state rows only (c = 2n); GOAL_COST — the state cost is (x-g)'Q(x-g) or x'Qx.
 struct Lat4Base {
   static constexpr int N = 4, M = 1;
   static constexpr int NA = 5, NB = 1;
+  static constexpr bool WRAPS = true, CTRL_ROWS = true, GOAL_COST = true;
   // compact A order: (0,2) (0,3) (1,2) (1,3) (2,3)
   __host__ __device__ static constexpr int a_slot(int i, int j) {
     return (i == 0 && j == 2) ? 0 : (i == 0 && j == 3) ? 1 : (i == 1 && j == 2) ? 2 : (i == 1 && j == 3) ? 3
@@ -114,10 +117,79 @@ struct Model<ALILQR_MODEL_LAT> : Lat4Base {
   }
 };
 
+// ---- lateral model with a squashed control (cilqr/lat_bicycle_interior_node.py) --------------------------------
+// delta_dot = control_max * tanh(u) (:55); f_u(3) = dt control_max (1 - tanh(u)^2) (:88); everything else as LAT.
+// control_max travels in ModelConst::k.  State bounds only, and the state cost does not subtract the goal (:96,106).
+template <>
+struct Model<ALILQR_MODEL_LAT_INTERIOR> : Lat4Base {
+  static constexpr int NB = 2;
+  static constexpr bool CTRL_ROWS = false, GOAL_COST = false;
+  // compact B order: (2,0) (3,0)
+  __host__ __device__ static constexpr int b_slot(int i, int j) { return (j == 0 && i == 2) ? 0 : (j == 0 && i == 3) ? 1 : -1; }
+  __host__ __device__ static constexpr int b_const(int, int) { return 0; }
+  template <bool WRAPPED = false>
+  __device__ static void step(const ModelConst& mc, const double* x, const double* u, double* xn) {
+    const double v = mc.v, dt = mc.dt, L = mc.L;
+    double th = wrap_in<WRAPPED>(x[2]), de = wrap_in<WRAPPED>(x[3]);
+    double s1, c1;
+    sincos_pi(th, &s1, &c1);
+    const double rate = mc.k * tanh(u[0]);
+    double k1[4] = {v * c1, v * s1, v * tan_pi(de) / L, rate};
+    double hdt = 0.5 * dt;
+    double mid[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mid[i] = x[i] + hdt * k1[i];
+    double thm = wrap_py(mid[2]), dem = wrap_py(mid[3]);
+    double s2, c2;
+    sincos_pi(thm, &s2, &c2);
+    double k2[4] = {v * c2, v * s2, v * tan_pi(dem) / L, rate};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xn[i] = x[i] + dt * k2[i];
+    xn[2] = wrap_py(xn[2]);
+    xn[3] = wrap_py(xn[3]);
+  }
+  template <bool WRAPPED = false>
+  __device__ static void jac(const ModelConst& mc, const double* x, const double* uc, double* a, double* b) {
+    Model<ALILQR_MODEL_LAT>::jac<WRAPPED>(mc, x, uc, a, b);       // :75-87 are the LAT expressions
+    const double th = tanh(uc[0]);
+    b[1] = mc.dt * mc.k * (1 - th * th);
+  }
+};
+
+// ---- longitudinal triple integrator (cilqr/lon_node.py) ----------------------------------------------------------
+// states (s, v, a), control jerk; RK2 of a linear system (:21-38); constant Jacobians (:49-60); no angles.
+template <>
+struct Model<ALILQR_MODEL_LON> {
+  static constexpr int N = 3, M = 1;
+  static constexpr int NA = 1, NB = 1;                 // a[0] = dt^2/2 at (0,2); b[0] unused (B is constant)
+  static constexpr bool WRAPS = false, CTRL_ROWS = true, GOAL_COST = true;
+  __host__ __device__ static constexpr int a_slot(int i, int j) { return (i == 0 && j == 2) ? 0 : -1; }
+  __host__ __device__ static constexpr bool a_is_dt(int i, int j) { return (i == 0 && j == 1) || (i == 1 && j == 2); }
+  __host__ __device__ static constexpr int b_slot(int, int) { return -1; }
+  __host__ __device__ static constexpr int b_const(int i, int j) { return (j == 0 && i == 1) ? 2 : (j == 0 && i == 2) ? 1 : 0; }
+  template <bool WRAPPED = false>
+  __device__ static void step(const ModelConst& mc, const double* x, const double* u, double* xn) {
+    const double dt = mc.dt, hdt = 0.5 * dt;
+    const double k1[3] = {x[1], x[2], u[0]};
+    double mid[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mid[i] = x[i] + hdt * k1[i];
+    const double k2[3] = {mid[1], mid[2], u[0]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xn[i] = x[i] + dt * k2[i];
+  }
+  template <bool WRAPPED = false>
+  __device__ static void jac(const ModelConst& mc, const double*, const double*, double* a, double* b) {
+    a[0] = 0.5 * (mc.dt * mc.dt);
+    b[0] = 0.0;
+  }
+};
+
 // ---- 6 states / 2 controls --------------------------------------------------
 struct Full6Base {
   static constexpr int N = 6, M = 2;
   static constexpr int NA = 11, NB = 1;
+  static constexpr bool WRAPS = true, CTRL_ROWS = true, GOAL_COST = true;
   // compact A order: row 0 cols 2..5, row 1 cols 2..5, row 2 cols 3..5 ; (4,5) is the constant dt
   __host__ __device__ static constexpr int a_slot(int i, int j) {
     return (i == 0 && j >= 2) ? (j - 2) : (i == 1 && j >= 2) ? (4 + j - 2) : (i == 2 && j >= 3) ? (8 + j - 3) : -1;

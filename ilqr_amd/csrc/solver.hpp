@@ -341,7 +341,7 @@ struct NodeOps;
 template <int MODEL>
 struct NodeOps<MODEL, ALILQR_MODE_LEGACY> {
   using MD = Model<MODEL>;
-  static constexpr int N = MD::N, M = MD::M, C = 2 * (N + M);
+  static constexpr int N = MD::N, M = MD::M, C = MD::CTRL_ROWS ? 2 * (N + M) : 2 * N;
 
   // constraint i of (x,u): [x - smax ; smin - x ; u - cmax ; cmin - u]
   __device__ static __forceinline__ double cval(ctab box, const double* x, const double* u, int i) {
@@ -356,7 +356,7 @@ struct NodeOps<MODEL, ALILQR_MODE_LEGACY> {
                                 const double* lam, size_t ls, double mu) {
     double e[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) e[i] = x[i] - g[i];
+    for (int i = 0; i < N; ++i) e[i] = MD::GOAL_COST ? x[i] - g[i] : x[i];
     double sc = a.qdiag ? quad_form_diag<N>(e, Q) : quad_form<N>(e, Q);
     double cc = quad_form<M>(u, R);
     double lc = 0.0, qc = 0.0;
@@ -396,7 +396,7 @@ struct NodeOps<MODEL, ALILQR_MODE_LEGACY> {
     using LL = LinLayout<MD>;
     double e[N], w[C], im[C];
 #pragma unroll
-    for (int i = 0; i < N; ++i) e[i] = x[i] - g[i];
+    for (int i = 0; i < N; ++i) e[i] = MD::GOAL_COST ? x[i] - g[i] : x[i];
 #pragma unroll
     for (int i = 0; i < C; ++i) {
       double c = cval(box, x, u, i);
@@ -419,11 +419,18 @@ struct NodeOps<MODEL, ALILQR_MODE_LEGACY> {
       double s = 0.0;
 #pragma unroll
       for (int j = 0; j < M; ++j) s += (2 * R[i * M + j]) * u[j];
-      rec[(LL::oLu + i) * rs] = s + (w[2 * N + i] - w[2 * N + M + i]);
+      if constexpr (MD::CTRL_ROWS) {
+        rec[(LL::oLu + i) * rs] = s + (w[2 * N + i] - w[2 * N + M + i]);
 #pragma unroll
-      for (int j = 0; j < M; ++j)
-        rec[(LL::oLuu + i * M + j) * rs] =
-            (i == j) ? (2 * R[i * M + j] + (im[2 * N + i] + im[2 * N + M + i])) : 2 * R[i * M + j];
+        for (int j = 0; j < M; ++j)
+          rec[(LL::oLuu + i * M + j) * rs] =
+              (i == j) ? (2 * R[i * M + j] + (im[2 * N + i] + im[2 * N + M + i])) : 2 * R[i * M + j];
+      } else {
+        // no control rows: C_u = 0 (lat_bicycle_interior_node.py:141), the sums of :111,122 add exact zeros
+        rec[(LL::oLu + i) * rs] = s + 0.0;
+#pragma unroll
+        for (int j = 0; j < M; ++j) rec[(LL::oLuu + i * M + j) * rs] = (i == j) ? (2 * R[i * M + j] + 0.0) : 2 * R[i * M + j];
+      }
     }
     (void)a;
   }
@@ -843,7 +850,7 @@ struct FxxOf<MD, true> {
 };
 
 template <int MODEL, int MODE, int G, bool LDSLIN = false>
-__global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) void solve_kernel(KArgs a) {
+__global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) void solve_kernel(KArgs a) {
   using MD = Model<MODEL>;
   using OPS = NodeOps<MODEL, MODE>;
   using LL = LinLayout<MD>;
@@ -857,9 +864,9 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
   // One roll-out pass per trip of the wave loop where a wave carries more than two groups (their line searches
   // need different numbers of passes); with two groups per wave the passes of a line search run back to back,
   // which also keeps the register allocation of the 6-state kernels tight.
-  constexpr bool TRIP = (G < 32) && (N == 4 || ALILQR_TRIP_N6);
+  constexpr bool TRIP = (G < 32) && (N <= 4 || ALILQR_TRIP_N6);
   constexpr bool PM = (G > 1);                         // block layout: problem-major (contiguous) or element-major
-  constexpr int CL = LEGACY ? 2 * (N + M) : 1;         // multipliers held in registers (LEGACY only)
+  constexpr int CL = LEGACY ? (MD::CTRL_ROWS ? 2 * (N + M) : 2 * N) : 1;         // multipliers held in registers (LEGACY only)
   constexpr int SS = TrjSlots<MODE>::SS;               // trajectory slots kept per problem and parity
 
   const int lane = threadIdx.x & 63;
@@ -1093,7 +1100,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N == 4 ? ALILQR_MINW_N4 : 1)) vo
               if (a.x_init) a.x_init[(size_t)p * XS + i] = x[i];
               a.x_out[(size_t)p * XS + i] = x[i];
               // node 0 keeps the wrapped start state from its first cost() call on (lat_bicycle_node.py:27-30,94)
-              *trj_at(0, i, cs) = (!NEWAL && (i == 2 || i == 3)) ? wrap_py(x[i]) : x[i];
+              *trj_at(0, i, cs) = (!NEWAL && MD::WRAPS && (i == 2 || i == 3)) ? wrap_py(x[i]) : x[i];
             }
           }
           for (int t = 0; t < H; ++t) {

@@ -382,6 +382,49 @@ class FullBicycleDynamicNode(_LegacyBoxNode):
         self.L, self.dt, self.k = L, dt, k
 
 
+class LongitudinalNode(_LegacyBoxNode):
+    """cilqr/lon_node.py:4-19 — 3 states (s, v, a), jerk control; linear dynamics, no angles."""
+    MODEL = "lon"
+
+    def __init__(self, dt, state_bounds, control_bounds, goal, Q, R):
+        self._init_box(state_bounds, control_bounds, goal, Q, R, 3, 1)
+        self.L, self.dt = 0.0, dt
+
+    def normalize_state(self):
+        pass
+
+
+class LatBicycleInteriorNode(_LegacyBoxNode):
+    """cilqr/lat_bicycle_interior_node.py:4-21 — lateral model whose steering rate is control_max * tanh(u).  Only
+    the states are bounded (8 rows); the state cost weighs the state itself, not its distance to the goal (:96)."""
+    MODEL = "lat_interior"
+
+    def __init__(self, L, dt, v, state_bounds, control_bounds, goal, Q, R):
+        self._init_box(state_bounds, control_bounds, goal, Q, R, 4, 1)
+        self.L, self.dt, self.v = L, dt, v
+        self._constraint_dim = 8
+        self._constraints = np.zeros(8)
+        self.lambda_ = np.zeros(8)
+        self.Imu = np.zeros((8, 8))
+
+    def model_constants(self):
+        # the k slot of the descriptor carries control_max[0] for this model
+        return (float(self.L), float(self.dt), float(self.v), float(self.control_max[0]))
+
+    def constraints(self):
+        self.normalize_state()
+        return np.hstack((self.state - self.state_max, self.state_min - self.state))
+
+    def constraint_jacobian(self):
+        n = self._state_dim
+        Jx = np.vstack((np.eye(n), -np.eye(n)))
+        return Jx, np.zeros((self._constraint_dim, self._control_dim))
+
+    def is_state_within_constraints(self):
+        self.normalize_state()
+        return not np.any((self.state > self.state_max) | (self.state < self.state_min))
+
+
 class FastILQRNode(_NodeCommon):
     """cilqr/fast_ilqr_node.py:5-78 — node with a pluggable ``Constraints`` object."""
     MODE = "fast"

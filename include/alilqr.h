@@ -31,6 +31,10 @@ extern "C" {
  * LAT_K    4 / 1 with the (1+k v^2) understeer factor    al_ilqr_cpp/model/new_lat_bicycle_node.h:27-163
  * NEW_BICYCLE 6 / 2 of the C++ generation                 al_ilqr_cpp/model/new_bicycle_node.h:228-650
  *          (same map as DYN_MID; its f_x heading row d/dv term and its angle wrap differ)
+ * LON      3 / 1 longitudinal triple integrator (s, v, a; jerk control), no angles   cilqr/lon_node.py:4-146
+ * LAT_INTERIOR 4 / 1 lateral model whose steering rate is control_max * tanh(u); state bounds only (c = 2n), the
+ *          state cost is x'Qx without the goal   cilqr/lat_bicycle_interior_node.py:4-174
+ *          (the descriptor's k carries control_max[0])
  */
 enum alilqr_model {
   ALILQR_MODEL_LAT = 0,
@@ -38,7 +42,9 @@ enum alilqr_model {
   ALILQR_MODEL_DYN = 2,
   ALILQR_MODEL_DYN_MID = 3,
   ALILQR_MODEL_LAT_K = 4,
-  ALILQR_MODEL_NEW_BICYCLE = 5
+  ALILQR_MODEL_NEW_BICYCLE = 5,
+  ALILQR_MODEL_LON = 6,
+  ALILQR_MODEL_LAT_INTERIOR = 7
 };
 
 /* ---- solver generation ---------------------------------------------------
@@ -103,13 +109,13 @@ typedef struct alilqr_problem {
   int32_t model;         /* enum alilqr_model */
   int32_t mode;          /* enum alilqr_mode  */
   int32_t horizon;       /* H: number of controls; H+1 nodes */
-  int32_t n, m, c;       /* state, control, constraint-row counts (LEGACY: c = 2(n+m)) */
+  int32_t n, m, c;       /* state, control, constraint-row counts (LEGACY: c = 2(n+m); LAT_INTERIOR: c = 2n) */
   int32_t batch;         /* B problems */
   int32_t goal_batch;    /* 1: all problems track the same goals; B: one goal list each */
   int32_t table_nodes;   /* 1: Q,R,constraint table shared by all nodes; H+1: one per node */
   int32_t cons_kind;     /* enum alilqr_cons_kind */
   int32_t reserved;      /* 0 */
-  double L, dt, v, k;    /* wheel base, step, (lat) speed, understeer factor */
+  double L, dt, v, k;    /* wheel base, step, (lat) speed, understeer factor (LAT_INTERIOR: control_max) */
   alilqr_params prm;
 } alilqr_problem;
 

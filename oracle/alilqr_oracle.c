@@ -107,7 +107,8 @@ static double py_mod(double a, double b) {
 }
 double or_wrap_py(double a) { return py_mod(a + OR_PI, 2.0 * OR_PI) - OR_PI; }
 
-static void normalize_state(or_node* nd) {   /* lat_bicycle_node.py:27-30 */
+static void normalize_state(or_node* nd) {   /* lat_bicycle_node.py:27-30 ; lon_node.py has no angles */
+  if (nd->model == ALILQR_MODEL_LON) return;
   nd->state[2] = or_wrap_py(nd->state[2]);
   nd->state[3] = or_wrap_py(nd->state[3]);
 }
@@ -118,6 +119,12 @@ static void normalize_state(or_node* nd) {   /* lat_bicycle_node.py:27-30 */
 /* lat_bicycle_node.py:48-56 ; full_bicycle_kinematic_node.py:47-58 ;
  * full_bicycle_dynamic_node.py:48-59 ; fast_bicycle_node.py:43-54 */
 static void dyn_cont(const or_node* nd, const double* s, const double* u, double* out) {
+  if (nd->model == ALILQR_MODEL_LON) {          /* lon_node.py:33-38 */
+    out[0] = s[1];
+    out[1] = s[2];
+    out[2] = u[0];
+    return;
+  }
   double theta = or_wrap_py(s[2]);
   double delta = or_wrap_py(s[3]);
   if (nd->model == ALILQR_MODEL_LAT) {
@@ -125,6 +132,13 @@ static void dyn_cont(const or_node* nd, const double* s, const double* u, double
     out[1] = nd->v * sin(theta);
     out[2] = nd->v * tan(delta) / nd->L;
     out[3] = u[0];
+    return;
+  }
+  if (nd->model == ALILQR_MODEL_LAT_INTERIOR) {  /* lat_bicycle_interior_node.py:48-56 ; k holds control_max[0] */
+    out[0] = nd->v * cos(theta);
+    out[1] = nd->v * sin(theta);
+    out[2] = nd->v * tan(delta) / nd->L;
+    out[3] = nd->k * tanh(u[0]);
     return;
   }
   double v = s[4], a = s[5];
@@ -147,6 +161,7 @@ void or_py_dynamics(const or_node* nd, const double* s, const double* u, double*
   for (int i = 0; i < n; ++i) mid[i] = s[i] + 0.5 * nd->dt * k1[i];
   dyn_cont(nd, mid, u, k2);
   for (int i = 0; i < n; ++i) next[i] = s[i] + nd->dt * k2[i];
+  if (nd->model == ALILQR_MODEL_LON) return;    /* lon_node.py:21-31 */
   next[2] = or_wrap_py(next[2]);
   next[3] = or_wrap_py(next[3]);
 }
@@ -157,9 +172,18 @@ void or_py_jacobian(const or_node* nd, const double* s, const double* uc, double
   memset(A, 0, sizeof(double) * n * n);
   memset(B, 0, sizeof(double) * n * m);
   for (int i = 0; i < n; ++i) A[i * n + i] = 1.0;
+  if (nd->model == ALILQR_MODEL_LON) {          /* lon_node.py:40-62 */
+    A[0 * 3 + 1] = dt;
+    A[0 * 3 + 2] = 0.5 * (dt * dt);
+    A[1 * 3 + 2] = dt;
+    B[1] = 0.5 * (dt * dt);
+    B[2] = dt;
+    return;
+  }
   double theta = or_wrap_py(s[2]);
   double delta = or_wrap_py(s[3]);
-  if (nd->model == ALILQR_MODEL_LAT) {          /* lat_bicycle_node.py:58-91 */
+  if (nd->model == ALILQR_MODEL_LAT || nd->model == ALILQR_MODEL_LAT_INTERIOR) {
+    /* lat_bicycle_node.py:58-91 ; lat_bicycle_interior_node.py:58-91 (same f_x, f_u(3) = dt u_max (1 - tanh(u)^2)) */
     double v = nd->v, u = uc[0];
     double td = tan(delta);
     double tm = theta + 0.5 * dt * v * td / L;
@@ -170,7 +194,12 @@ void or_py_jacobian(const or_node* nd, const double* s, const double* uc, double
     A[1 * 4 + 3] = 0.5 * (dt * dt) * (v * v) * (td * td + 1) * cos(tm) / L;
     A[2 * 4 + 3] = dt * v * (tu * tu + 1) / L;
     B[2] = 0.5 * (dt * dt) * v * (tu * tu + 1) / L;
-    B[3] = dt;
+    if (nd->model == ALILQR_MODEL_LAT_INTERIOR) {
+      double th = tanh(u);
+      B[3] = dt * nd->k * (1 - th * th);
+    } else {
+      B[3] = dt;
+    }
     return;
   }
   double v = s[4], a = s[5], u1 = uc[0];
@@ -271,6 +300,7 @@ static void legacy_constraints(or_node* nd, double* c) {   /* :127-133 */
   int n = nd->n, m = nd->m;
   for (int i = 0; i < n; ++i) c[i] = nd->state[i] - nd->smax[i];
   for (int i = 0; i < n; ++i) c[n + i] = nd->smin[i] - nd->state[i];
+  if (nd->model == ALILQR_MODEL_LAT_INTERIOR) return;   /* state rows only: lat_bicycle_interior_node.py:125-130 */
   for (int j = 0; j < m; ++j) c[2 * n + j] = nd->control[j] - nd->cmax[j];
   for (int j = 0; j < m; ++j) c[2 * n + m + j] = nd->cmin[j] - nd->control[j];
 }
@@ -293,7 +323,8 @@ static double quad_form(int n, const double* e, const double* Q) {   /* e.T @ Q 
 static double legacy_cost(or_node* nd) {                   /* :93-102 */
   double e[OR_NX], c[OR_NC];
   normalize_state(nd);
-  for (int i = 0; i < nd->n; ++i) e[i] = nd->state[i] - nd->goal[i];
+  /* lat_bicycle_interior_node.py:96 weighs the state itself, the other nodes the distance to the goal */
+  for (int i = 0; i < nd->n; ++i) e[i] = (nd->model == ALILQR_MODEL_LAT_INTERIOR) ? nd->state[i] : nd->state[i] - nd->goal[i];
   double state_cost = quad_form(nd->n, e, nd->Q);
   double control_cost = quad_form(nd->m, nd->control, nd->R);
   legacy_update_Imu(nd);
@@ -309,7 +340,7 @@ static void legacy_cost_jacobian(or_node* nd, double* Jx, double* Ju) {   /* :10
   double e[OR_NX], c[OR_NC], w[OR_NC];
   int n = nd->n, m = nd->m;
   normalize_state(nd);
-  for (int i = 0; i < n; ++i) e[i] = nd->state[i] - nd->goal[i];
+  for (int i = 0; i < n; ++i) e[i] = (nd->model == ALILQR_MODEL_LAT_INTERIOR) ? nd->state[i] : nd->state[i] - nd->goal[i];
   for (int i = 0; i < n; ++i) {
     double s = 0.0;
     for (int j = 0; j < n; ++j) s += (2 * nd->Q[i * n + j]) * e[j];
@@ -326,6 +357,10 @@ static void legacy_cost_jacobian(or_node* nd, double* Jx, double* Ju) {   /* :10
   /* C_x = [I; -I; 0; 0], C_u = [0; 0; I; -I]: the dense products of :112-113
    * reduce to two non-zero terms each, so this is the same arithmetic */
   for (int i = 0; i < n; ++i) Jx[i] = Jx[i] + (w[i] - w[n + i]);
+  if (nd->model == ALILQR_MODEL_LAT_INTERIOR) {        /* C_u = 0 (:141): the product adds zeros */
+    for (int j = 0; j < m; ++j) Ju[j] = Ju[j] + 0.0;
+    return;
+  }
   for (int j = 0; j < m; ++j) Ju[j] = Ju[j] + (w[2 * n + j] - w[2 * n + m + j]);
 }
 static void legacy_cost_hessian(or_node* nd, double* Hx, double* Hu) {    /* :117-125 */
@@ -334,6 +369,7 @@ static void legacy_cost_hessian(or_node* nd, double* Hx, double* Hu) {    /* :11
   for (int i = 0; i < m * m; ++i) Hu[i] = 2 * nd->R[i];
   legacy_update_Imu(nd);
   for (int i = 0; i < n; ++i) Hx[i * n + i] = Hx[i * n + i] + (nd->Imu[i] + nd->Imu[n + i]);
+  if (nd->model == ALILQR_MODEL_LAT_INTERIOR) return;
   for (int j = 0; j < m; ++j) Hu[j * m + j] = Hu[j * m + j] + (nd->Imu[2 * n + j] + nd->Imu[2 * n + m + j]);
 }
 static void legacy_update_lambda(or_node* nd) {            /* :162-165 */

@@ -34,8 +34,10 @@ def problem_from_golden(g, idx=None):
         cons = capi.pack_linear(A, B, Cv)
         c = A.shape[0]
     eq = ("eq" in g.files) and bool(g["eq"])
+    # the interior node's steering rate is control_max * tanh(u): control_max travels in the k slot
+    k = float(g["control_max"][0]) if model == "lat_interior" else float(g["k"])
     desc = capi.make_problem(model, mode, H, x0.shape[0], float(g["L"]), float(g["dt"]),
-                             v=float(g["v"]), k=float(g["k"]), c=c,
+                             v=float(g["v"]), k=k, c=c,
                              cons_kind=capi.CONS_EQUALITY if eq else capi.CONS_LINEAR)
     goals = np.ascontiguousarray(g["goals"], dtype=np.float64)
     return desc, x0, goals, np.ascontiguousarray(g["Q"], dtype=np.float64), \

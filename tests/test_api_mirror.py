@@ -111,12 +111,45 @@ def test_fast_node_packs_its_constraint_object():
         FastILQR([eq_nodes[0]] + nodes[1:])._describe(1, 20, 1e-8)
 
 
+def test_longitudinal_and_interior_nodes_host_side():
+    """cilqr/lon_node.py and cilqr/lat_bicycle_interior_node.py: dimensions, constraint helpers, descriptor."""
+    from ilqr_amd.nodes import LatBicycleInteriorNode, LongitudinalNode
+    lon = [LongitudinalNode(dt=0.1, state_bounds=np.array([[-10, 0, -2], [10, 14, 2.0]]), control_bounds=np.array([[-3], [3.0]]),
+                            goal=np.array([t, 10.0, 0]), Q=np.eye(3), R=np.eye(1)) for t in range(4)]
+    nd = lon[0]
+    assert (nd.state_dim, nd.control_dim, nd.constraint_dim) == (3, 1, 8)
+    nd.state = np.array([11.0, 5.0, 4.0]); nd.control = np.array([-4.0])      # no angle wrap on a[2] = 4
+    c = nd.constraints()
+    assert np.allclose(c, [1, -9, 2, -21, -5, -6, -7, 1]) and nd.state[2] == 4.0
+    assert not nd.is_state_within_constraints()
+    desc = ILQR(lon)._describe(5, 20, 1e-8)[0]
+    assert (desc.model, desc.n, desc.m, desc.c, desc.horizon, desc.batch) == (capi.MODELS["lon"], 3, 1, 8, 3, 5)
+    with pytest.raises(ValueError, match="Invalid state dimension"):
+        nd.state = np.zeros(4)
+
+    sb = np.array([[-1000, -1000, -0.05, -0.05], [1000, 1000, 0.05, 0.05]])
+    itr = [LatBicycleInteriorNode(L=1.0, dt=0.1, v=10.0, state_bounds=sb, control_bounds=np.array([[-0.3], [0.3]]),
+                                  goal=np.zeros(4), Q=np.eye(4), R=np.eye(1)) for _ in range(3)]
+    nd = itr[0]
+    assert (nd.state_dim, nd.control_dim, nd.constraint_dim) == (4, 1, 8) and nd.lambda_.shape == (8,)
+    nd.state = np.array([0.0, 0.0, 4.0, 0.1])
+    c = nd.constraints()
+    assert c.shape == (8,) and abs(nd.state[2] - (4.0 - 2 * np.pi)) < 1e-12 and abs(c[3] - 0.05) < 1e-15
+    Jx, Ju = nd.constraint_jacobian()
+    assert Jx.shape == (8, 4) and not Ju.any()
+    nd.set_mu(2.0); nd.update_lambda()
+    assert np.allclose(nd.get_lambda(), np.maximum(0, 2.0 * c))
+    desc, goals, Q, R, cons = ILQR(itr)._describe(2, 20, 1e-8)
+    assert (desc.model, desc.c, desc.k) == (capi.MODELS["lat_interior"], 8, 0.3) and cons.shape == (1, 10)
+
+
 def test_flat_module_names_of_the_reference_import(monkeypatch):
     import os, sys, importlib
     compat = os.path.join(os.path.dirname(capi.__file__), "compat")
     monkeypatch.syspath_prepend(compat)
     for mod, name in (("lat_bicycle_node", "LatBicycleKinematicNode"), ("ilqr", "ILQR"), ("fast_ilqr", "FastILQR"),
-                      ("box_constrains", "BoxConstraint"), ("fast_bicycle_node", "FastBicycleNode")):
+                      ("box_constrains", "BoxConstraint"), ("fast_bicycle_node", "FastBicycleNode"),
+                      ("lon_node", "LongitudinalNode"), ("lat_bicycle_interior_node", "LatBicycleInteriorNode")):
         sys.modules.pop(mod, None)
         m = importlib.import_module(mod)
         assert hasattr(m, name)

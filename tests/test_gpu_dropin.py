@@ -168,3 +168,52 @@ def test_pybind_shaped_rectangle_obstacle_flow():
     assert gu.rel_err(x.T, ref["x"][0]) < 1e-6 and s.last_status["inner"] == ref["status"][0, 0]
     inside = (x[0] > 28) & (x[0] < 32) & (x[1] > 13) & (x[1] < 15)
     assert not inside.any()
+
+
+def test_longitudinal_and_interior_nodes_run_under_ilqr():
+    """The two remaining legacy nodes (cilqr/lon_node.py, cilqr/lat_bicycle_interior_node.py) through
+    ILQR(nodes).optimize() and their own methods, against vectors recorded from the reference."""
+    from ilqr_amd.nodes import LatBicycleInteriorNode, LongitudinalNode
+    g = gu.load("lon_legacy")
+    sb = np.array([g["state_min"], g["state_max"]]); cb = np.array([g["control_min"], g["control_max"]])
+    nodes = [LongitudinalNode(dt=0.1, state_bounds=sb, control_bounds=cb, goal=goal, Q=g["Q"], R=g["R"]) for goal in g["goals"]]
+    i = int(np.nonzero(g["stable"])[0][0])
+    solver = ILQR(nodes)
+    nodes[0].state = g["x0"][i]
+    x_init, u_init, x, u = solver.optimize()
+    for got, key in ((x_init, "x_init"), (u_init, "u_init"), (x, "x"), (u, "u")):
+        assert gu.rel_err(got, g[key][i]) < TOL, key
+    assert gu.rel_err(np.array([nd.lambda_ for nd in nodes]), g["lam"][i]) < TOL
+    assert solver.last_status["outer"] == g["n_outer"][i] and solver.last_status["inner"] == g["n_inner"][i]
+
+    g = gu.load("interior_legacy")
+    sb = np.array([g["state_min"], g["state_max"]]); cb = np.array([g["control_min"], g["control_max"]])
+    nodes = [LatBicycleInteriorNode(L=1.0, dt=0.1, v=10.0, state_bounds=sb, control_bounds=cb, goal=goal, Q=g["Q"], R=g["R"])
+             for goal in g["goals"]]
+    assert nodes[0].constraint_dim == 8
+    capped = np.nonzero(g["stable"] & (g["n_outer"] == 20))[0]
+    for i in (int(np.nonzero(g["stable"])[0][0]), int(capped[0])):
+        solver = ILQR(nodes)
+        nodes[0].state = g["x0"][i]
+        _, _, x, u = solver.optimize()
+        assert gu.rel_err(x, g["x"][i]) < TOL and gu.rel_err(u, g["u"][i]) < TOL
+        assert solver.last_status["outer"] == g["n_outer"][i]
+
+    k = gu.load("nodes_kat_extra")
+    pre = "legacy_lat_interior_"
+    sb = np.array([k[pre + "state_min"], k[pre + "state_max"]]); cb = np.array([k[pre + "control_min"], k[pre + "control_max"]])
+    nd = LatBicycleInteriorNode(float(k[pre + "L"]), float(k[pre + "dt"]), float(k[pre + "v"]), sb, cb, k[pre + "goal"],
+                                k[pre + "Q"], k[pre + "R"])
+    for i in range(4):
+        X, U = k[pre + "X"][i], k[pre + "U"][i]
+        assert gu.rel_err(nd.dynamics(X.copy(), U.copy()), k[pre + "f"][i]) < 1e-12
+        A, B = nd.dynamics_jacobian(X.copy(), U.copy())
+        assert gu.rel_err(A, k[pre + "fx"][i]) < 1e-12 and gu.rel_err(B, k[pre + "fu"][i]) < 1e-12
+        nd.state = X.copy(); nd.control = U.copy(); nd.set_lambda(k[pre + "LAM"][i].copy()); nd.set_mu(float(k[pre + "MU"][i]))
+        assert abs(nd.cost() - k[pre + "l"][i]) < 1e-12 * max(1, abs(k[pre + "l"][i]))
+        jx, ju = nd.cost_jacobian(); hx, hu = nd.cost_hessian()
+        assert gu.rel_err(jx, k[pre + "lx"][i]) < 1e-12 and gu.rel_err(hx, k[pre + "lxx"][i]) < 1e-12
+        assert gu.rel_err(ju, k[pre + "lu"][i]) < 1e-12 and gu.rel_err(hu, k[pre + "luu"][i]) < 1e-12
+        assert gu.rel_err(nd.constraints(), k[pre + "cons"][i]) < 1e-15
+        nd.update_lambda()
+        assert gu.rel_err(nd.lambda_, k[pre + "lam_new"][i]) < 1e-12

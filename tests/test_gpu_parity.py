@@ -51,7 +51,8 @@ def lanes(request, monkeypatch):
     return int(request.param)
 
 
-@pytest.mark.parametrize("name", ["lat_legacy", "dyn_legacy", "kin_legacy", "fast_box", "fast_linear", "fast_equality"])
+@pytest.mark.parametrize("name", ["lat_legacy", "dyn_legacy", "kin_legacy", "fast_box", "fast_linear", "fast_equality",
+                                  "lon_legacy", "interior_legacy"])
 def test_golden_sets(name, lanes):
     """GPU vs the reference's own vectors and vs the oracle, every lane-group width."""
     g = gu.load(name)
@@ -228,18 +229,19 @@ def test_solves_on_different_streams_overlap_and_match():
 
 @pytest.mark.parametrize("tag,model,mode", [("legacy_lat", "lat", "legacy"), ("legacy_dyn", "dyn", "legacy"),
                                              ("fast_box", "dyn_mid", "fast"), ("fast_linear", "dyn_mid", "fast"),
-                                             ("fast_equality", "dyn_mid", "fast")])
+                                             ("fast_equality", "dyn_mid", "fast"),
+                                             ("legacy_lon", "lon", "legacy"), ("legacy_lat_interior", "lat_interior", "legacy")])
 def test_node_aux_kernel_matches_reference_vectors(tag, model, mode):
     """alilqr_node_aux_batch: constraint values, one multiplier update and the violation term against the
     reference's golden points (and the oracle for the legacy violation term, which the goldens do not hold)."""
-    k = gu.load("nodes_kat")
+    k = gu.load("nodes_kat_extra" if model in ("lon", "lat_interior") else "nodes_kat")
     pre = tag + "_"
     X, U, LAM, MU = k[pre + "X"], k[pre + "U"], k[pre + "LAM"], k[pre + "MU"]
     N = X.shape[0]
     if mode == "legacy":
         cons = capi.pack_box(k[pre + "state_min"], k[pre + "state_max"], k[pre + "control_min"], k[pre + "control_max"])
-        desc = capi.make_problem(model, mode, 1, N, float(k[pre + "L"]), float(k[pre + "dt"]), v=float(k[pre + "v"]),
-                                 k=float(k[pre + "k"]))
+        kk = float(k[pre + "control_max"][0]) if model == "lat_interior" else float(k[pre + "k"])
+        desc = capi.make_problem(model, mode, 1, N, float(k[pre + "L"]), float(k[pre + "dt"]), v=float(k[pre + "v"]), k=kk)
     else:
         cons = capi.pack_linear(k[pre + "A"], k[pre + "B"], k[pre + "C"])
         desc = capi.make_problem(model, mode, 1, N, float(k[pre + "L"]), float(k[pre + "dt"]), k=float(k[pre + "k"]),

@@ -14,7 +14,12 @@ def main():
             "dyn_legacy": lambda: problems.full_legacy("dyn", B, 60, 3),
             "circle6": lambda: problems.new_al_circle(B), "lat_circle": lambda: problems.new_al_lat_circle(B)}
     kw = {}
-    if name in ("lat_rect", "kin_rect"):
+    if name.startswith("golden:"):
+        # the first B problems of a golden set, e.g. golden:lon_legacy
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import golden_util as gu
+        desc, x0, goals, Q, R, cons = gu.problem_from_golden(gu.load(name[7:]), idx=list(range(B)))
+    elif name in ("lat_rect", "kin_rect"):
         (desc, x0, goals, Q, R, cons), kw = (problems.new_al_lat_rect if name == "lat_rect" else problems.kin_rect)(B)
     else:
         desc, x0, goals, Q, R, cons = sets[name]()

@@ -16,6 +16,9 @@ Sets written to tests/golden/:
   fast_box.npz          FastILQR + FastBicycleNode + BoxConstraint (test_fast_full.py setup)
   fast_linear.npz       FastILQR + FastBicycleNode(k=0) + LinearConstraints (box rows + half-planes)
   fast_equality.npz     FastILQR + FastBicycleNode(k=0) + LinearConstraints(is_equality=True)
+  lon_legacy.npz        ILQR + LongitudinalNode (triple integrator, active control / acceleration bounds)
+  interior_legacy.npz   ILQR + LatBicycleInteriorNode (tanh-squashed steering rate, state bounds only)
+  nodes_kat_extra.npz   per-call known answers of those two nodes
 """
 import argparse
 import contextlib
@@ -39,7 +42,9 @@ def _import_ref():
     import fast_ilqr as ref_fast_ilqr
     import lat_bicycle_node, full_bicycle_kinematic_node, full_bicycle_dynamic_node
     import fast_bicycle_node, linear_constraints, box_constrains
+    import lon_node, lat_bicycle_interior_node
     return dict(
+        Lon=lon_node.LongitudinalNode, Interior=lat_bicycle_interior_node.LatBicycleInteriorNode,
         ILQR=ref_ilqr.ILQR, FastILQR=ref_fast_ilqr.FastILQR,
         Lat=lat_bicycle_node.LatBicycleKinematicNode,
         Kin=full_bicycle_kinematic_node.FullBicycleKinematicNode,
@@ -101,6 +106,43 @@ def full_x0(B, seed):
     x0[:, 2] = r[:, 1]
     x0[:, 4] = 10.0 + r[:, 2]
     return x0
+
+
+def lon_problem(H=50):
+    """LongitudinalNode (cilqr/lon_node.py): follow a 10 m/s reference with bounded acceleration and jerk."""
+    t = np.arange(H + 1) * 0.1
+    goals = np.stack([10.0 * t, np.full_like(t, 10.0), np.zeros_like(t)], axis=1)
+    return dict(model="lon", mode="legacy", H=H, L=0.0, dt=0.1, v=0.0, k=0.0,
+                Q=np.diag([1.0, 1.0, 0.1]), R=np.array([[0.5]]),
+                state_min=np.array([-1000, 0.0, -2.0]), state_max=np.array([1000, 14.0, 2.0]),
+                control_min=np.array([-3.0]), control_max=np.array([3.0]), goals=goals)
+
+
+def lon_x0(B, seed):
+    rng = np.random.default_rng(seed)
+    r = rng.uniform([-2.0, -3.0, -0.5], [2.0, 3.0, 0.5], size=(B, 3))
+    r[:, 1] += 10.0
+    return r
+
+
+def interior_problem(H=50):
+    """LatBicycleInteriorNode (cilqr/lat_bicycle_interior_node.py): regulate y, heading and steering to zero along
+    the x axis; the steering rate is control_max * tanh(u), the table holds state bounds only."""
+    t = np.arange(H + 1) * 0.1
+    goals = np.stack([10.0 * t, np.zeros_like(t), np.zeros_like(t), np.zeros_like(t)], axis=1)
+    return dict(model="lat_interior", mode="legacy", H=H, L=1.0, dt=0.1, v=10.0, k=0.0,
+                Q=np.diag([0.0, 1.0, 1.0, 1e-3]), R=np.array([[1.0]]),
+                state_min=np.array([-1000, -1000, -0.05, -0.05]),
+                state_max=np.array([1000, 1000, 0.05, 0.05]),
+                control_min=np.array([-0.3]), control_max=np.array([0.3]), goals=goals)
+
+
+def interior_x0(B, seed):
+    """(0, U(-1,1), U(-0.03,0.03), U(-0.02,0.02)): inside the heading / steering bounds of interior_problem; the
+    larger lateral offsets make the heading bound active."""
+    rng = np.random.default_rng(seed)
+    r = rng.uniform([-1.0, -0.03, -0.02], [1.0, 0.03, 0.02], size=(B, 3))
+    return np.concatenate([np.zeros((B, 1)), r], axis=1)
 
 
 def fast_box_problem(H=50):
@@ -195,6 +237,10 @@ def _build_nodes(ref, p):
             cb = np.array([p["control_min"], p["control_max"]])
             if p["model"] == "lat":
                 nd = ref["Lat"](L=p["L"], dt=p["dt"], v=p["v"], state_bounds=sb, control_bounds=cb, goal=g, Q=p["Q"], R=p["R"])
+            elif p["model"] == "lon":
+                nd = ref["Lon"](dt=p["dt"], state_bounds=sb, control_bounds=cb, goal=g, Q=p["Q"], R=p["R"])
+            elif p["model"] == "lat_interior":
+                nd = ref["Interior"](L=p["L"], dt=p["dt"], v=p["v"], state_bounds=sb, control_bounds=cb, goal=g, Q=p["Q"], R=p["R"])
             elif p["model"] == "kin":
                 nd = ref["Kin"](L=p["L"], dt=p["dt"], state_bounds=sb, control_bounds=cb, goal=g, Q=p["Q"], R=p["R"])
             else:
@@ -379,6 +425,53 @@ def node_kats():
     print("nodes_kat: written", len(out), "arrays", flush=True)
 
 
+def node_kats_extra():
+    """Known answers of LongitudinalNode and LatBicycleInteriorNode (own file and own random stream, so the
+    vectors of nodes_kat.npz stay what they are)."""
+    ref = _import_ref()
+    rng = np.random.default_rng(4321)
+    out = {}
+    N = 24
+    for model, p in (("lon", lon_problem(4)), ("lat_interior", interior_problem(4))):
+        n = p["Q"].shape[0]; m = 1
+        if model == "lon":
+            p["state_min"] = np.array([-3.0, 8.0, -1.0]); p["state_max"] = np.array([3.0, 12.0, 1.0])
+            scale = np.array([5, 3.0, 2.0]); shift = np.array([0, 10.0, 0])
+        else:
+            p["state_min"] = -np.array([3, 3, 1.0, 0.3]); p["state_max"] = np.array([3, 3, 1.0, 0.3])
+            scale = np.array([5, 5, 4.0, 0.6]); shift = np.zeros(4)
+        nodes = _build_nodes(ref, p)
+        nd = nodes[1]
+        c = nd.constraint_dim
+        X = rng.uniform(-1, 1, size=(N, n)) * scale + shift
+        U = rng.uniform(-1, 1, size=(N, m)) * (4.0 if model == "lon" else 1.5)
+        LAM = np.maximum(0, rng.uniform(-1, 1, size=(N, c)))
+        MU = rng.uniform(0.5, 20, size=N)
+        rec = {k: [] for k in ("f", "fx", "fu", "l", "lx", "lu", "lxx", "luu", "cons", "lam_new", "xnorm")}
+        for i in range(N):
+            rec["f"].append(nd.dynamics(X[i].copy(), U[i].copy()))
+            a, b = nd.dynamics_jacobian(X[i].copy(), U[i].copy())
+            rec["fx"].append(np.array(a, dtype=float)); rec["fu"].append(np.array(b, dtype=float))
+            nd.state = X[i].copy(); nd.control = U[i].copy()
+            nd.set_lambda(LAM[i].copy()); nd.set_mu(float(MU[i]))
+            rec["l"].append(float(nd.cost()))
+            jx, ju = nd.cost_jacobian(); rec["lx"].append(jx); rec["lu"].append(ju)
+            hx, hu = nd.cost_hessian(); rec["lxx"].append(hx); rec["luu"].append(hu)
+            rec["cons"].append(nd.constraints().copy())
+            rec["xnorm"].append(nd.state.copy())
+            nd.update_lambda(); rec["lam_new"].append(nd.lambda_.copy())
+        pre = f"legacy_{model}_"
+        for k_, v_ in rec.items():
+            out[pre + k_] = np.array(v_)
+        out[pre + "X"] = X; out[pre + "U"] = U; out[pre + "LAM"] = LAM; out[pre + "MU"] = MU
+        for k_ in ("L", "dt", "v", "k", "Q", "R", "state_min", "state_max", "control_min", "control_max"):
+            out[pre + k_] = np.array(p[k_])
+        out[pre + "goal"] = np.array(nd.goal)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "nodes_kat_extra.npz"), **out)
+    print("nodes_kat_extra: written", len(out), "arrays", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -390,6 +483,12 @@ def main():
     want = lambda n: a.only is None or a.only == n
     if want("nodes_kat"):
         node_kats()
+    if want("nodes_kat_extra"):
+        node_kats_extra()
+    if want("lon_legacy"):
+        run_set("lon_legacy", lon_problem(50), lon_x0(a.kin, 7), a.jobs)
+    if want("interior_legacy"):
+        run_set("interior_legacy", interior_problem(50), interior_x0(a.kin, 8), a.jobs)
     if want("lat_legacy"):
         x0 = np.concatenate([np.zeros((1, 4)), lat_x0(a.lat - 1, 0)])
         run_set("lat_legacy", lat_problem(50), x0, a.jobs)

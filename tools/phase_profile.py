@@ -35,13 +35,13 @@ def main():
     buf = (C.c_ulonglong * 9)()
     assert lib.alilqr_prof_read(buf) == 0
     v = np.array(list(buf), dtype=np.float64)
-    names = ["pull+init", "outer-start cost", "P1 linearise", "P2 riccati", "P3 rollouts", "P4 bookkeeping", "-", "loop top"]
+    names = ["pull+init", "outer-start cost", "P1 linearise", "P2 riccati", "P3 rollouts", "P4 bookkeeping", "-", "group 0 idle, others busy"]
     waves = v[8]
     tot = v[:8].sum()
     st = o["status"].cpu().numpy()
     print(f"lanes={os.environ.get('ALILQR_LANES','auto')} B={B} kernel {e0.elapsed_time(e1):.1f} ms  waves {int(waves)}  mean wave busy {tot/waves/1e6:.1f} Mcycles  mean inner {st[:,0].mean():.1f}")
     for n, x in zip(names, v[:8]):
-        print(f"  {n:18s} {100*x/tot:6.2f} %   {x/waves/1e6:8.2f} Mcyc/wave")
+        print(f"  {n:26s} {100*x/tot:6.2f} %   {x/waves/1e6:8.2f} Mcyc/wave")
 
 if __name__ == "__main__":
     main()
