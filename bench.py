@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (HIP streams used in turn)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) is the product path; gloo only rehearses the multi-rank control flow on a box "
+                         "with fewer GPUs than ranks (ranks then share devices and the gather goes through the host)")
     args = ap.parse_args()
 
     import torch
@@ -80,19 +83,25 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     B, H = args.batch, 50
     desc, x0, goals, Q, R, cons = problems.lat_legacy(B, H, seed=rank)
     depth = max(1, min(4, args.pipeline))
     solvers = [batch.BatchSolver(desc, x0, goals, Q, R, cons, extras=False, device=dev) for _ in range(depth)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
-    gathered = [torch.empty((world * B,), dtype=torch.float64, device=dev) if world > 1 else None for _ in range(depth)]
+    gdev = dev if args.backend == "nccl" else torch.device("cpu")
+    gathered = [torch.empty((world * B,), dtype=torch.float64, device=gdev) if world > 1 else None for _ in range(depth)]
     torch.cuda.synchronize(dev)
 
     def step(k, ev=None):
@@ -104,7 +113,10 @@ def main():
             if ev is not None:
                 ev[1].record(streams[i])
             if world > 1:
-                dist.all_gather_into_tensor(gathered[i], out["cost"])
+                if args.backend == "nccl":
+                    dist.all_gather_into_tensor(gathered[i], out["cost"])
+                else:
+                    dist.all_gather_into_tensor(gathered[i], out["cost"].cpu())
         return out
 
     for k in range(args.warmup):
@@ -123,7 +135,7 @@ def main():
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
