@@ -156,7 +156,7 @@ def main():
 
     if rank == 0:
         # counters of the same launch, collected in separate rocprofv3 --pmc passes (tools/profile_round.sh)
-        traffic = valu_active = None
+        traffic = valu_active = executed = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
         if os.path.exists(pmc):
             try:
@@ -166,7 +166,7 @@ def main():
                 if counters.get("SQ_WAVE_CYCLES"):
                     valu_active = counters["SQ_ACTIVE_INST_VALU"] / counters["SQ_WAVE_CYCLES"]
             except (OSError, ValueError, KeyError):
-                traffic = valu_active = None
+                traffic = valu_active = executed = None
         line = {
             "metric": "converged AL-iLQR solves/sec (H=50, batch N)",
             "value": world * B * args.steps / dt,
@@ -193,6 +193,10 @@ def main():
             "roofline": {"bound": "valu_fp64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
                          "valu_active_share_of_wave_cycles": valu_active,
+                         # fp64 flops the hardware executed (FMA, ADD, MUL instruction counters x 64 lanes, masked lanes
+                         # included) over the job's wall time: the machine-side utilisation beside the algorithmic one
+                         "executed_fp64_TFLOPs_job": (executed * args.steps / dt / 1e12) if executed else None,
+                         "executed_fp64_frac_job": (executed * args.steps / dt / 1e12 / FP64_VALU_PEAK_TFLOPS) if executed else None,
                          "kernel": "alilqr::solve_kernel", "kernel_ms": kernel_ms,
                          "achieved_job": tf_job, "frac_job": tf_job / FP64_VALU_PEAK_TFLOPS,
                          "algorithmic_flops_per_launch": flops,

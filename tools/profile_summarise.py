@@ -34,7 +34,7 @@ def counters(d):
 lines = []
 f = find(tag + "_kt", "*kernel_stats.csv")
 if f:
-    lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2")
+    lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py")
     lines.append("name | calls | total_ns | avg_ns | pct")
     for r in csv.DictReader(open(f)):
         lines.append(f"{r['Name']} | {r['Calls']} | {r['TotalDurationNs']} | {r['AverageNs']} | {r['Percentage']}")
@@ -78,6 +78,22 @@ if sq:
     w = sq.get("SQ_WAVE_CYCLES")
     if w:
         out.append(f"wait share SQ_WAIT_ANY/SQ_WAVE_CYCLES = {sq['SQ_WAIT_ANY'] / w:.3f} ; VALU-active share = {sq['SQ_ACTIVE_INST_VALU'] / w:.3f}")
+# extra passes of tools/pmc_extra.sh: issue stalls, instruction cache, executed instruction mix
+for name, what in (("stall", "wave-cycle breakdown"), ("icache", "instruction cache"), ("mix", "executed VALU instruction mix")):
+    c, n = counters(tag + "_x_" + name)
+    if not c:
+        continue
+    out.append(f"rocprofv3 --pmc {' '.join(sorted(c))} -- python3 bench.py --steps 1 --warmup 0 --no-cpu   ({what})")
+    for k, v in sorted(c.items()):
+        out.append(f"{k} {v / n:.6g}")
+        summary[k] = v / n
+    if name == "stall" and c.get("SQ_WAVE_CYCLES"):
+        w = c["SQ_WAVE_CYCLES"]
+        out.append("shares of wave cycles: " + " ; ".join(f"{k} {c[k] / w:.3f}" for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if k in c))
+    if name == "mix":
+        fl = (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0)) * 64 / n
+        summary["executed_fp64_lane_flops_per_launch"] = fl
+        out.append(f"executed fp64 flops per launch, all 64 lanes of every issued instruction counted = {fl:.6g}")
 if out:
     open(os.path.join(P, tag + "_pmc.txt"), "w").write("\n".join(out) + "\n")
     json.dump(summary, open(os.path.join(P, tag + "_pmc.json"), "w"), indent=1)
