@@ -61,6 +61,13 @@ def test_bad_descriptors_are_rejected_before_any_device_work():
     bad = capi.make_problem("dyn_mid", "legacy", 50, 4, 1.0, 0.1)
     assert call(bad) == capi.E_ARG
     assert lib.alilqr_workspace_bytes(C.byref(desc)) > 0
+    # the two extra legacy nodes: LON (3 states, 8 rows), LAT_INTERIOR (state rows only: c = 2n)
+    assert lib.alilqr_workspace_bytes(C.byref(capi.make_problem("lon", "legacy", 50, 4, 0.0, 0.1))) > 0
+    ok = capi.make_problem("lat_interior", "legacy", 50, 4, 1.0, 0.1, v=10.0, k=0.3)
+    assert ok.c == 8 and lib.alilqr_workspace_bytes(C.byref(ok)) > 0
+    ok.c = 10
+    assert lib.alilqr_workspace_bytes(C.byref(ok)) == capi.E_ARG and b"c = 2n" in lib.alilqr_last_error()
+    assert lib.alilqr_workspace_bytes(C.byref(capi.make_problem("lon", "fast", 50, 4, 0.0, 0.1, c=8))) == capi.E_ARG
     empty = capi.make_problem("lat", "legacy", 50, 0, 1.0, 0.1, v=10.0)
     assert call(empty) == 0                               # an empty batch is valid and touches nothing
 
