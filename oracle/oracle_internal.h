@@ -6,7 +6,7 @@
 
 #define OR_NX 6
 #define OR_NU 2
-#define OR_NC 32
+#define OR_NC 64   /* the row count the C ABI accepts */
 #define OR_PI 3.141592653589793
 
 /* One trajectory node of the Python generations: model + cost + AL state. */

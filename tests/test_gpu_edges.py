@@ -1,0 +1,98 @@
+"""Edge cases of the solve path on the GPU against the CPU oracle: the shortest horizons, the largest constraint
+table the ABI takes (64 rows), per-node tables in the FAST and NEW_AL generations, a single problem.
+
+Tolerance 1e-6 relative on x, u and the final cost on the solves the oracle reproduces from a start state moved by
+1e-13; NEW_AL cases are parity-unpinned against the C++ reference (the oracle is this build's restatement).
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle_lib as ol
+from ilqr_amd import batch, capi, problems
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def to_np(out):
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def worst_err(o, ref, i):
+    w = max(gu.rel_err(o["x"][i], ref["x"][i]), gu.rel_err(o["u"][i], ref["u"][i]),
+            abs(o["cost"][i] - ref["cost"][i]) / max(1.0, abs(ref["cost"][i])))
+    return w if np.isfinite(w) else np.inf
+
+
+def check(prob, floor=0.5, **kw):
+    desc, x0 = prob[0], prob[1]
+    ref = ol.solve_batch(*prob, **kw)
+    o = to_np(batch.solve_batch(*prob, **kw))
+    bump = np.zeros_like(x0); bump[:, 1] = 1e-13
+    ref2 = ol.solve_batch(desc, x0 + bump, *prob[2:6], **kw)
+    ok = np.array([worst_err(ref2, ref, i) < 1e-8 for i in range(desc.batch)])
+    assert ok.mean() >= floor, ok.mean()
+    for i in np.nonzero(ok)[0]:
+        assert worst_err(o, ref, i) < TOL, (i, o["status"][i], ref["status"][i])
+    assert gu.rel_err(o["x_init"], ref["x_init"]) < 1e-12
+    return o, ref
+
+
+GENERATORS = {
+    "legacy_lat": lambda B, H: problems.lat_legacy(B, H, seed=21),
+    "legacy_dyn": lambda B, H: problems.full_legacy("dyn", B, H, 22),
+    "fast_box": lambda B, H: problems.fast_box(B, H, seed=23),
+    "new_al_box6": lambda B, H: problems.new_al_box(B, H, seed=24),
+    "new_al_lat4": lambda B, H: problems.new_al_lat(B, H, seed=25),
+}
+
+
+@pytest.mark.parametrize("H", [1, 2, 3])
+@pytest.mark.parametrize("name", list(GENERATORS))
+def test_shortest_horizons(name, H):
+    o, ref = check(GENERATORS[name](12, H))
+    assert o["x"].shape[1] == H + 1 and o["u"].shape[1] == H
+
+
+@pytest.mark.parametrize("name", list(GENERATORS))
+def test_single_problem(name):
+    check(GENERATORS[name](1, 20), floor=0.0)
+
+
+@pytest.mark.parametrize("mode", ["fast", "new_al"])
+def test_sixty_four_constraint_rows(mode):
+    """The box rows of the 6-state node followed by 48 rows that can never be active (0 x + 0 u - 1 <= 0)."""
+    base = problems.fast_box(16, 30, seed=26) if mode == "fast" else problems.new_al_box(16, 30, seed=26, y_max=20.0)
+    desc, x0, goals, Q, R, cons = base
+    c0 = desc.c
+    A = cons[:c0 * 6].reshape(c0, 6); Bm = cons[c0 * 6:c0 * 8].reshape(c0, 2); C = cons[c0 * 8:]
+    A64 = np.vstack([A, np.zeros((64 - c0, 6))]); B64 = np.vstack([Bm, np.zeros((64 - c0, 2))])
+    C64 = np.concatenate([C, -np.ones(64 - c0)])
+    d64 = type(desc).from_buffer_copy(desc); d64.c = 64
+    o64, _ = check((d64, x0, goals, Q, R, capi.pack_linear(A64, B64, C64)), floor=0.3)
+    o = to_np(batch.solve_batch(*base))
+    # rows that are never active change nothing but the width of the multiplier arrays
+    assert gu.rel_err(o64["x"], o["x"]) < 1e-9 and gu.rel_err(o64["lam"][:, :, :c0], o["lam"]) < 1e-9
+    assert not o64["lam"][:, :, c0:].any()
+    d65 = type(desc).from_buffer_copy(desc); d65.c = 65
+    with pytest.raises(RuntimeError):
+        batch.solve_batch(d65, x0, goals, Q, R, np.zeros(65 * 9))
+
+
+@pytest.mark.parametrize("mode", ["fast", "new_al"])
+def test_per_node_tables(mode):
+    """table_nodes = H + 1: every node has its own Q, R and constraint table (here: a terminal weight ten times
+    larger and a y-bound that tightens along the horizon)."""
+    H, B = 30, 12
+    desc, x0, goals, Q, R, cons = problems.fast_box(B, H, seed=27) if mode == "fast" else problems.new_al_box(B, H, seed=27)
+    c = desc.c
+    d = type(desc).from_buffer_copy(desc); d.table_nodes = H + 1
+    Qn = np.tile(Q, (H + 1, 1, 1)); Qn[H] *= 10.0
+    Rn = np.tile(R, (H + 1, 1, 1))
+    Cn = np.tile(cons, (H + 1, 1))
+    for t in range(H + 1):
+        Cn[t, c * 8 + 1] = -(40.0 - 0.5 * t)           # row 1 is  y - y_max <= 0
+    o, ref = check((d, x0, goals, Qn, Rn, Cn), floor=0.3)
+    shared = to_np(batch.solve_batch(desc, x0, goals, Q, R, cons))
+    assert np.abs(shared["x"] - o["x"]).max() > 1e-3    # the per-node tables were used
