@@ -19,7 +19,8 @@ def build():
     return out
 
 def main():
-    path = build()
+    # PROF_LIB: another profiling build (e.g. one linked from per-family objects compiled with -DALILQR_PROF)
+    path = os.environ.get("PROF_LIB") or build()
     if len(sys.argv) > 1 and sys.argv[1] == "build":
         return
     from ilqr_amd import capi, batch, problems
@@ -27,7 +28,11 @@ def main():
     lib = capi.load_library()
     import torch
     B = int(os.environ.get("B", "4096"))
-    desc, x0, goals, Q, R, cons = problems.lat_legacy(B, 50, seed=0)
+    workloads = {"lat_legacy": lambda: problems.lat_legacy(B, 50, seed=0),
+                 "dyn_legacy_h100": lambda: problems.full_legacy("dyn", B, 100, 2),
+                 "fast_box": lambda: problems.fast_box(B), "new_al_box6": lambda: problems.new_al_box(B)}
+    wl = os.environ.get("WORKLOAD", "lat_legacy")
+    desc, x0, goals, Q, R, cons = workloads[wl]()
     s = batch.BatchSolver(desc, x0, goals, Q, R, cons)
     s.run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,7 +44,7 @@ def main():
     waves = v[8]
     tot = v[:8].sum()
     st = o["status"].cpu().numpy()
-    print(f"lanes={os.environ.get('ALILQR_LANES','auto')} B={B} kernel {e0.elapsed_time(e1):.1f} ms  waves {int(waves)}  mean wave busy {tot/waves/1e6:.1f} Mcycles  mean inner {st[:,0].mean():.1f}")
+    print(f"{wl} lanes={os.environ.get('ALILQR_LANES','auto')} B={B} kernel {e0.elapsed_time(e1):.1f} ms  waves {int(waves)}  mean wave busy {tot/waves/1e6:.1f} Mcycles  mean inner {st[:,0].mean():.1f}")
     for n, x in zip(names, v[:8]):
         print(f"  {n:26s} {100*x/tot:6.2f} %   {x/waves/1e6:8.2f} Mcyc/wave")
 
