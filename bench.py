@@ -63,7 +63,7 @@ def cpu_baseline(sample, seconds_hint=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--cpu-sample", type=int, default=4096)
@@ -165,6 +165,7 @@ def main():
                 traffic = counters.get("hbm_bytes_per_launch")
                 if counters.get("SQ_WAVE_CYCLES"):
                     valu_active = counters["SQ_ACTIVE_INST_VALU"] / counters["SQ_WAVE_CYCLES"]
+                executed = counters.get("executed_fp64_lane_flops_per_launch")
             except (OSError, ValueError, KeyError):
                 traffic = valu_active = executed = None
         line = {
