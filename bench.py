@@ -8,10 +8,12 @@ resident in HBM before the timed region; every rank owns its own batch (weak
 scaling, no collective inside the solve; the per-step gather of the cost vector
 over RCCL is the only exchange).
 
-Consecutive steps are independent batches.  They are enqueued on --pipeline (default 3) HIP streams in turn, each
-with its own output buffers and its own scratch inside the library, so the next batch fills the SIMDs that the
-tail of the previous one leaves idle (a batch ends when its longest solve ends; the mean wave is busy ~40 % of a
-lone launch).  All K steps complete inside the timed region; --pipeline 1 gives the one-launch-at-a-time number.
+Consecutive steps are independent batches.  They are enqueued on --pipeline (default 6) HIP streams in turn, each
+with its own output buffers and its own scratch inside the library, so the next batches fill the SIMDs that the
+tail of a batch leaves idle (a batch ends when its longest solve ends; the mean wave is busy ~40 % of a lone
+launch).  The process asks the HIP runtime for 16 hardware queues (--hw-queues): with the default 4, streams share
+queues and their kernels run one after the other.  All K steps complete inside the timed region; --pipeline 1
+gives the one-launch-at-a-time number.
 
   python bench.py --gpus N --steps K --warmup W
 """
@@ -68,12 +70,17 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (HIP streams used in turn)")
+    ap.add_argument("--pipeline", type=int, default=6, help="batches in flight (HIP streams used in turn)")
+    ap.add_argument("--hw-queues", type=int, default=16,
+                    help="GPU_MAX_HW_QUEUES for this process (HIP's default of 4 makes streams share a hardware "
+                         "queue, and kernels on one queue run one after the other); 0 leaves the environment's value")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) is the product path; gloo only rehearses the multi-rank control flow on a box "
                          "with fewer GPUs than ranks (ranks then share devices and the gather goes through the host)")
     args = ap.parse_args()
 
+    if args.hw_queues > 0:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(min(32, args.hw_queues))     # read by the HIP runtime when it starts
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,11 +104,15 @@ def main():
 
     B, H = args.batch, 50
     desc, x0, goals, Q, R, cons = problems.lat_legacy(B, H, seed=rank)
-    depth = max(1, min(4, args.pipeline))
+    depth = max(1, min(8, args.pipeline))
     solvers = [batch.BatchSolver(desc, x0, goals, Q, R, cons, extras=False, device=dev) for _ in range(depth)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
     gathered = [torch.empty((world * B,), dtype=torch.float64, device=gdev) if world > 1 else None for _ in range(depth)]
+    # set-up, not a step: every stream's first solve allocates that stream's scratch inside the library
+    for sv, st in zip(solvers, streams):
+        with torch.cuda.stream(st):
+            sv.run(st.cuda_stream)
     torch.cuda.synchronize(dev)
 
     def step(k, ev=None):
