@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--hw-queues", type=int, default=16,
                     help="GPU_MAX_HW_QUEUES for this process (HIP's default of 4 makes streams share a hardware "
                          "queue, and kernels on one queue run one after the other); 0 leaves the environment's value")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: take the multi-rank path (process group, per-step gather, barriers) with one rank too")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) is the product path; gloo only rehearses the multi-rank control flow on a box "
                          "with fewer GPUs than ranks (ranks then share devices and the gather goes through the host)")
@@ -95,7 +97,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -108,7 +111,7 @@ def main():
     solvers = [batch.BatchSolver(desc, x0, goals, Q, R, cons, extras=False, device=dev) for _ in range(depth)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
-    gathered = [torch.empty((world * B,), dtype=torch.float64, device=gdev) if world > 1 else None for _ in range(depth)]
+    gathered = [torch.empty((world * B,), dtype=torch.float64, device=gdev) if multi else None for _ in range(depth)]
     # set-up, not a step: every stream's first solve allocates that stream's scratch inside the library
     for sv, st in zip(solvers, streams):
         with torch.cuda.stream(st):
@@ -123,7 +126,7 @@ def main():
             out = solvers[i].run(streams[i].cuda_stream)
             if ev is not None:
                 ev[1].record(streams[i])
-            if world > 1:
+            if multi:
                 if args.backend == "nccl":
                     dist.all_gather_into_tensor(gathered[i], out["cost"])
                 else:
@@ -133,7 +136,7 @@ def main():
     for k in range(args.warmup):
         step(k)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize(dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -141,11 +144,11 @@ def main():
     for k in range(args.steps):
         out = step(k, ev[k])
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -221,7 +224,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
