@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = the library's choice)")
     ap.add_argument("--pipeline", type=int, default=6, help="batches in flight (HIP streams used in turn)")
     ap.add_argument("--hw-queues", type=int, default=16,
                     help="GPU_MAX_HW_QUEUES for this process (HIP's default of 4 makes streams share a hardware "
@@ -105,6 +106,8 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    if args.lanes:
+        capi.set_tuning(lanes=args.lanes)
     B, H = args.batch, 50
     desc, x0, goals, Q, R, cons = problems.lat_legacy(B, H, seed=rank)
     depth = max(1, min(8, args.pipeline))
@@ -207,7 +210,7 @@ def main():
             "config": {"workload": "lat-bicycle AL-iLQR (ILQR + LatBicycleKinematicNode, box constraints), H=50, "
                                    f"batch {B} per GPU, start states x0=(0,U(-1,1),U(-0.2,0.2),U(-0.05,0.05)) seed=rank",
                        "batch_per_gpu": B, "horizon": H, "mode": "legacy", "model": "lat",
-                       "lanes_per_problem": os.environ.get("ALILQR_LANES", "auto"),
+                       "lanes_per_problem": args.lanes or "auto",
                        "batches_in_flight": depth, "lone_launch_ms": lone_ms,
                        # latency of one iLQR iteration (linearise, backward sweep, line search) of one problem with the
                        # whole batch resident: a lone launch lasts as long as its longest solve

@@ -110,15 +110,23 @@ class BatchSolver:
 
     def run(self, stream_ptr=None):
         torch = _torch()
-        if stream_ptr is None:
-            stream_ptr = torch.cuda.current_stream(self.dev).cuda_stream
         o = self.out
-        rc = self.lib.alilqr_solve_batch(C.byref(self.desc), *[_ptr(t) for t in self.inputs],
-                                         _ptr(o["x"]), _ptr(o["u"]), _ptr(o.get("node_x")), _ptr(o.get("node_u")),
-                                         None, None, _ptr(o["cost"]), _ptr(o.get("viol")), None, _ptr(o.get("mu")),
-                                         _ptr(o["status"]), C.c_void_p(stream_ptr))
+        fn = self.lib.alilqr_solve_batch
+        # the library launches on the device that is current on the calling thread
+        with torch.cuda.device(self.dev):
+            if stream_ptr is None:
+                stream_ptr = torch.cuda.current_stream(self.dev).cuda_stream
+            rc = fn(C.byref(self.desc), *[_ptr(t) for t in self.inputs],
+                    _ptr(o["x"]), _ptr(o["u"]), _ptr(o.get("node_x")), _ptr(o.get("node_u")),
+                    None, None, _ptr(o["cost"]), _ptr(o.get("viol")), None, _ptr(o.get("mu")),
+                    _ptr(o["status"]), C.c_void_p(stream_ptr))
         capi.check(rc, "alilqr_solve_batch")
         return o
+
+
+def release():
+    """Free the library's cached device scratch (waits for the solves in flight)."""
+    capi.release()
 
 
 def linearize_batch(desc, x, u, lam, mu, goals, Q, R, cons, device="cuda:0"):

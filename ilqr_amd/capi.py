@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 STATUS_WORDS = 4
 
 MODELS = {"lat": 0, "kin": 1, "dyn": 2, "dyn_mid": 3, "lat_k": 4, "new_bicycle": 5, "lon": 6, "lat_interior": 7}
@@ -131,7 +131,7 @@ LIB_PATH = os.environ.get("ALILQR_LIB") or os.path.join(os.path.dirname(os.path.
 EXPORTS = ("alilqr_abi_version", "alilqr_last_error", "alilqr_device_count", "alilqr_default_params",
            "alilqr_workspace_bytes", "alilqr_solve_batch", "alilqr_solve_batch_multistart", "alilqr_solve_batch_ex",
            "alilqr_linearize_batch", "alilqr_node_aux_batch",
-           "alilqr_release")
+           "alilqr_release", "alilqr_set_tuning")
 
 
 class LibraryMissing(RuntimeError):
@@ -171,10 +171,22 @@ def load_library():
     lib.alilqr_node_aux_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 14
     lib.alilqr_linearize_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17
     lib.alilqr_release.restype = C.c_int32
+    lib.alilqr_set_tuning.restype = C.c_int32
+    lib.alilqr_set_tuning.argtypes = [C.c_int32] * 3
     if lib.alilqr_abi_version() != ABI_VERSION:
         raise RuntimeError("libalilqr_hip.so ABI version mismatch")
     _LIB = lib
     return lib
+
+
+def set_tuning(lanes=0, max_waves=0, no_lds=0):
+    """Process-wide tuning / diagnostic overrides of the library (0 = automatic); results do not depend on them."""
+    check(load_library().alilqr_set_tuning(int(lanes), int(max_waves), int(bool(no_lds))), "alilqr_set_tuning")
+
+
+def release():
+    """Free every cached device workspace of the library (waits for the solves in flight)."""
+    check(load_library().alilqr_release(), "alilqr_release")
 
 
 def last_error():

@@ -5,6 +5,7 @@
 // returns ALILQR_E_NODEVICE / ALILQR_E_HIP.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,19 +42,31 @@ void set_err(const char* fmt, const char* a = "", const char* b = "") {
     }                                                                        \
   } while (0)
 
-// Grow-only device scratch, one per (device, stream): solves enqueued on different streams of a device may
-// overlap on the GPU (the tail of one batch leaves most of the machine idle, the next batch fills it), so each
-// stream works in its own scratch.
-struct Workspace {
+// Device scratch.  A solve needs scratch for its resident lane groups only (they pull problems from a counter),
+// so a slot is a few hundred MB at most.  Slots form a pool per device: a solve takes the slot its stream used
+// last (stream order already serialises the two kernels), else a slot whose last kernel has finished (its event
+// says so), else a new slot, else - the pool is full - the least recently used slot, after which the stream
+// waits for that slot's event on the GPU.  Every reuse is preceded by hipStreamWaitEvent on the slot's last event,
+// so a recycled stream handle or a slot handed to another stream can never overlap its previous kernel.  The pool
+// lock is held until the kernel is enqueued and the slot's event recorded: a grow or a release on another thread
+// cannot free scratch that a launch is about to use.
+struct Slot {
   void* ptr = nullptr;
   size_t bytes = 0;
-  hipStream_t stream = nullptr;
-  bool used = false;
+  hipStream_t stream = nullptr;   // stream of the last solve in this slot
+  hipEvent_t done = nullptr;      // recorded behind the last solve in this slot
+  bool used = false;              // a solve has been enqueued in this slot
+  unsigned counter_next = 0;      // value the slot's problem counter holds once its last solve has finished
+  unsigned long long tick = 0;    // for least-recently-used
 };
-constexpr int kMaxDev = 16, kMaxStreams = 8;
-Workspace g_ws[kMaxDev][kMaxStreams];
+constexpr int kMaxDev = 16, kMaxSlots = 32;
+Slot g_slots[kMaxDev][kMaxSlots];
+unsigned long long g_tick = 0;
 void* g_last_ws[kMaxDev] = {};   // scratch of the most recent solve on the device (profiling builds read it)
 std::mutex g_mu;
+
+// Tuning overrides (alilqr_set_tuning): 0 = automatic.
+std::atomic<int> g_opt_lanes{0}, g_opt_max_waves{0}, g_opt_no_lds{0};
 
 struct Dims {
   int N, M, NA, NB, E;
@@ -120,8 +133,8 @@ int32_t check_problem(const alilqr_problem* p, Dims* d) {
 // batch fits in 2 waves per SIMD at that width, the next narrower one beyond; a single lane per problem never
 // wins (its roll-outs are sequential and the kernel spills).
 int pick_group(const alilqr_problem* p) {
-  if (const char* e = std::getenv("ALILQR_LANES")) {
-    int g = std::atoi(e);
+  {
+    const int g = g_opt_lanes.load(std::memory_order_relaxed);
     if (g == 1 || g == 4 || g == 8 || g == 16 || g == 32) return g;
   }
   const long target_waves = 2048;   // 2 waves on each of the 1024 SIMDs
@@ -162,26 +175,40 @@ size_t block_doubles_for(const alilqr_problem* p, bool rect) {
   return block_doubles<Model<ALILQR_MODEL_DYN_MID>, ALILQR_MODE_FAST>(H, C);
 }
 
-Plan make_plan(const alilqr_problem* p, const Dims& d, bool rect = false) {
+// Layout of a solve's scratch.  `cap` > 0 bounds the total: the number of resident waves is reduced until the
+// scratch fits (the groups then pull more problems each); total == 0 says that not even one wave fits.
+Plan make_plan(const alilqr_problem* p, const Dims& d, bool rect = false, size_t cap = 0) {
   Plan pl{};
   pl.G = pick_group(p);
   long max_waves = 4096;
-  if (const char* e = std::getenv("ALILQR_MAX_WAVES")) { long w = std::atol(e); if (w > 0) max_waves = w; }
+  { const long w = g_opt_max_waves.load(std::memory_order_relaxed); if (w > 0) max_waves = w; }
   long gpw = 64 / pl.G;                             // groups per wave
   long need_waves = ((long)p->batch + gpw - 1) / gpw;
   long waves = need_waves < max_waves ? need_waves : max_waves;
   if (waves < 1) waves = 1;
-  pl.NG = (int)(waves * gpw);
   const size_t H = p->horizon, N = d.N, M = d.M;
   const size_t T = (H + 1) * N + H * M;
-  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  size_t off = 0;
-  pl.counter = off; off = up(off + 256);
   const size_t SS = (p->mode == ALILQR_MODE_LEGACY) ? alilqr::TrjSlots<ALILQR_MODE_LEGACY>::SS : alilqr::TrjSlots<ALILQR_MODE_FAST>::SS;
-  pl.trj = off; off = up(off + sizeof(double) * 2 * T * (size_t)pl.NG * SS);
-  pl.ucum = off; off = up(off + sizeof(double) * H * M * (size_t)pl.NG * pl.G);
-  pl.blk = off; off = up(off + sizeof(double) * block_doubles_for(p, rect) * (size_t)pl.NG);
-  pl.total = off;
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  auto lay = [&](long w) {
+    pl.NG = (int)(w * gpw);
+    size_t off = 0;
+    pl.counter = off; off = up(off + 256);
+    pl.trj = off; off = up(off + sizeof(double) * 2 * T * (size_t)pl.NG * SS);
+    pl.ucum = off; off = up(off + sizeof(double) * H * M * (size_t)pl.NG * pl.G);
+    pl.blk = off; off = up(off + sizeof(double) * block_doubles_for(p, rect) * (size_t)pl.NG);
+    pl.total = off;
+  };
+  lay(waves);
+  if (cap > 0 && pl.total > cap) {
+    lay(1);
+    const size_t per_wave = pl.total;               // upper bound of what one more wave adds (alignment included)
+    if (per_wave > cap) { pl.total = 0; return pl; }
+    long fit = (long)(cap / per_wave);
+    if (fit > waves) fit = waves;
+    lay(fit);
+    while (pl.total > cap && fit > 1) lay(--fit);
+  }
   return pl;
 }
 
@@ -356,16 +383,50 @@ int32_t alilqr_solve_batch_multistart(const alilqr_problem* p,
                                cost, viol, lam, mu, status, stream);
 }
 
-int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
-                              const double* x0, const double* goals,
-                              const double* Q, const double* R, const double* cons,
-                              const alilqr_extras* ex,
-                              double* x_out, double* u_out,
-                              double* node_x, double* node_u,
-                              double* x_init, double* u_init,
-                              double* cost, double* viol,
-                              double* lam, double* mu,
-                              int32_t* status, void* stream) {
+// Take a scratch slot of the pool for a solve of `bytes` on stream `st` (pool lock held by the caller).
+static int32_t take_slot(int dev, hipStream_t st, size_t bytes, Slot** out) {
+  Slot* pool = g_slots[dev];
+  Slot* slot = nullptr;
+  for (int i = 0; i < kMaxSlots && !slot; ++i)             // the slot this stream used last
+    if (pool[i].used && pool[i].stream == st) slot = &pool[i];
+  for (int i = 0; i < kMaxSlots && !slot; ++i)             // a slot whose last kernel has finished
+    if (pool[i].used && hipEventQuery(pool[i].done) == hipSuccess) slot = &pool[i];
+  for (int i = 0; i < kMaxSlots && !slot; ++i)             // a slot never used
+    if (!pool[i].used) slot = &pool[i];
+  if (!slot) {                                             // pool full and busy: queue behind the least recently used
+    slot = &pool[0];
+    for (int i = 1; i < kMaxSlots; ++i)
+      if (pool[i].tick < slot->tick) slot = &pool[i];
+  }
+  if (!slot->done) HIP_TRY(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+  if (slot->used) HIP_TRY(hipStreamWaitEvent(st, slot->done, 0));   // orders this solve behind the slot's last one
+  if (slot->bytes < bytes) {
+    if (slot->ptr) {
+      // the old block may still be read by the slot's last kernel
+      if (slot->used) HIP_TRY(hipEventSynchronize(slot->done));
+      HIP_TRY(hipFree(slot->ptr));
+      slot->ptr = nullptr; slot->bytes = 0;
+    }
+    hipError_t e = hipMalloc(&slot->ptr, bytes);
+    if (e != hipSuccess) { set_err("hipMalloc(workspace): %s", hipGetErrorString(e)); slot->ptr = nullptr; return ALILQR_E_NOMEM; }
+    slot->bytes = bytes;
+    HIP_TRY(hipMemsetAsync(slot->ptr, 0, 256, st));         // counter block of the new scratch
+    slot->counter_next = 0;
+  }
+  *out = slot;
+  return ALILQR_OK;
+}
+
+static int32_t solve_impl(const alilqr_problem* p,
+                          const double* x0, const double* goals,
+                          const double* Q, const double* R, const double* cons,
+                          const alilqr_extras* ex,
+                          double* x_out, double* u_out,
+                          double* node_x, double* node_u,
+                          double* x_init, double* u_init,
+                          double* cost, double* viol,
+                          double* lam, double* mu,
+                          int32_t* status, void* stream) {
   const double* u_offset = ex ? ex->u_offset : nullptr;
   const int n_left = ex ? ex->n_left : 0, n_right = ex ? ex->n_right : 0;
   const bool rect = (n_left > 0) || (n_right > 0);
@@ -392,29 +453,21 @@ int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
   if (dev < 0 || dev >= kMaxDev) { set_err("device index out of range"); return ALILQR_E_ARG; }
   hipStream_t st = (hipStream_t)stream;
   Plan pl = make_plan(p, d, rect);
+
+  // The pool lock is held until the kernel is enqueued: nothing can free or re-assign the scratch in between.
+  std::lock_guard<std::mutex> lk(g_mu);
   char* base = nullptr;
+  unsigned* counter_next = nullptr;
+  Slot* slot = nullptr;
   {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Workspace* slot = nullptr;
-    for (int i = 0; i < kMaxStreams && !slot; ++i)
-      if (g_ws[dev][i].used && g_ws[dev][i].stream == st) slot = &g_ws[dev][i];
-    for (int i = 0; i < kMaxStreams && !slot; ++i)
-      if (!g_ws[dev][i].used) { slot = &g_ws[dev][i]; slot->used = true; slot->stream = st; }
-    if (!slot) { set_err("more than 8 streams solve on this device; call alilqr_release() to start over"); return ALILQR_E_ARG; }
-    Workspace& w = *slot;
-    if (w.bytes < pl.total) {
-      if (w.ptr) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(w.ptr)); w.ptr = nullptr; w.bytes = 0; }
-      hipError_t e = hipMalloc(&w.ptr, pl.total);
-      if (e != hipSuccess) { set_err("hipMalloc(workspace): %s", hipGetErrorString(e)); w.ptr = nullptr; return ALILQR_E_NOMEM; }
-      w.bytes = pl.total;
-      // counters start at zero; every solve leaves them at zero again (kernel epilogue)
-      HIP_TRY(hipMemsetAsync((char*)w.ptr + pl.counter, 0, 256, st));
-    }
-    g_last_ws[dev] = w.ptr;
-    base = (char*)w.ptr;
+    rc = take_slot(dev, st, pl.total, &slot);
+    if (rc != ALILQR_OK) return rc;
+    base = (char*)slot->ptr;
+    counter_next = &slot->counter_next;
+    g_last_ws[dev] = slot->ptr;
   }
 #ifdef ALILQR_PROF
-  HIP_TRY(hipMemsetAsync(base + pl.counter, 0, 256, st));   /* profiling builds keep their phase counters here too */
+  HIP_TRY(hipMemsetAsync(base + pl.counter + 128, 0, 128, st));   /* phase counters of profiling builds */
 #endif
 
   alilqr::KArgs ka{};
@@ -431,21 +484,54 @@ int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
   ka.status = status;
   ka.trj = (double*)(base + pl.trj); ka.blk = (double*)(base + pl.blk); ka.ucum = (double*)(base + pl.ucum);
   ka.counter = (unsigned int*)(base + pl.counter);
-  ka.prof = (unsigned long long*)(base + pl.counter + 128);   // zeroed with the counter; read by profiling builds
+  // The problem counter is never reset: a solve starts from the value the scratch's previous solve left, which
+  // the host knows exactly - every problem is pulled once and every group makes one failing pull at the end.
+  ka.counter_base = *counter_next;
+  ka.prof = (unsigned long long*)(base + pl.counter + 128);   // read by profiling builds
   const int waves = pl.NG * pl.G / 64;
 
   // kernel family = model x kernel mode (families.inc)
   const int kmode = (p->mode == ALILQR_MODE_NEW_AL) ? new_al_variant(p, rect) : p->mode;
-  const int no_lds = std::getenv("ALILQR_NO_LDS") ? 1 : 0;
+  const int no_lds = g_opt_no_lds.load(std::memory_order_relaxed) ? 1 : 0;
   int lr = -1;
 #define X(m, k) if (p->model == (m) && kmode == (k)) lr = alilqr::ALILQR_FAMILY_NAME(m, k)(ka, pl.G, waves, st, no_lds);
 #include "families.inc"
 #undef X
-  if (lr == alilqr::LAUNCH_OK) return ALILQR_OK;
+  if (lr == alilqr::LAUNCH_OK) {
+    *counter_next += (unsigned)p->batch + (unsigned)pl.NG;
+    if (slot) {
+      HIP_TRY(hipEventRecord(slot->done, st));
+      slot->used = true; slot->stream = st; slot->tick = ++g_tick;
+    }
+    return ALILQR_OK;
+  }
   if (lr == alilqr::LAUNCH_BAD_WIDTH) { set_err("bad lane-group width"); return ALILQR_E_ARG; }
   if (lr == alilqr::LAUNCH_FAILED) { set_err("kernel launch failed"); return ALILQR_E_HIP; }
   set_err("unsupported model / mode combination (or a development build without this kernel family)");
   return ALILQR_E_ARG;
+}
+
+int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
+                              const double* x0, const double* goals,
+                              const double* Q, const double* R, const double* cons,
+                              const alilqr_extras* ex,
+                              double* x_out, double* u_out,
+                              double* node_x, double* node_u,
+                              double* x_init, double* u_init,
+                              double* cost, double* viol,
+                              double* lam, double* mu,
+                              int32_t* status, void* stream) {
+  return solve_impl(p, x0, goals, Q, R, cons, ex, x_out, u_out, node_x, node_u, x_init, u_init,
+                    cost, viol, lam, mu, status, stream);
+}
+
+int32_t alilqr_set_tuning(int32_t lanes, int32_t max_waves, int32_t no_lds) {
+  if (!(lanes == 0 || lanes == 1 || lanes == 4 || lanes == 8 || lanes == 16 || lanes == 32)) {
+    set_err("lanes must be 0 (automatic), 1, 4, 8, 16 or 32"); return ALILQR_E_ARG;
+  }
+  if (max_waves < 0) { set_err("max_waves must be >= 0"); return ALILQR_E_ARG; }
+  g_opt_lanes.store(lanes); g_opt_max_waves.store(max_waves); g_opt_no_lds.store(no_lds ? 1 : 0);
+  return ALILQR_OK;
 }
 
 static int32_t node_eval(const alilqr_problem* p,
@@ -537,16 +623,18 @@ int32_t alilqr_release(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (int i = 0; i < kMaxDev; ++i) {
     bool any = false;
-    for (int k = 0; k < kMaxStreams; ++k) any |= (g_ws[i][k].ptr != nullptr);
+    for (int k = 0; k < kMaxSlots; ++k) any |= (g_slots[i][k].ptr != nullptr) || (g_slots[i][k].done != nullptr);
     int cur = 0;
     if (any && hipGetDevice(&cur) == hipSuccess) {
       (void)hipSetDevice(i);
       (void)hipDeviceSynchronize();
-      for (int k = 0; k < kMaxStreams; ++k)
-        if (g_ws[i][k].ptr) (void)hipFree(g_ws[i][k].ptr);
+      for (int k = 0; k < kMaxSlots; ++k) {
+        if (g_slots[i][k].ptr) (void)hipFree(g_slots[i][k].ptr);
+        if (g_slots[i][k].done) (void)hipEventDestroy(g_slots[i][k].done);
+      }
       (void)hipSetDevice(cur);
     }
-    for (int k = 0; k < kMaxStreams; ++k) g_ws[i][k] = Workspace{};
+    for (int k = 0; k < kMaxSlots; ++k) g_slots[i][k] = Slot{};
     g_last_ws[i] = nullptr;
   }
   return ALILQR_OK;

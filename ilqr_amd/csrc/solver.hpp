@@ -76,7 +76,8 @@ struct KArgs {
   double *x_out, *u_out, *node_x, *node_u, *x_init, *u_init, *cost, *viol, *lam, *mu;
   int32_t* status;
   double *trj, *blk, *ucum;
-  unsigned int* counter;
+  unsigned int* counter;      // problem counter of the scratch, never reset: this solve's problems are
+  unsigned int counter_base;  // counter - counter_base = 0 .. B-1 (the host knows the value every solve leaves behind)
   unsigned long long* prof;   // optional phase cycle counters (profiling builds only)
 };
 
@@ -997,7 +998,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
     // ================= problem switch: pull + initial guess =================
     if (p < 0 && !drained) {
       int np = 0;
-      if (gl == 0) np = (int)atomicAdd(a.counter, 1u);
+      if (gl == 0) np = (int)(atomicAdd(a.counter, 1u) - a.counter_base);
       np = gbcast_i<G>(np, 0);
       if (np >= a.B) {
         drained = true;
@@ -1683,18 +1684,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
     }
   }
   PROF_FLUSH(a)
-  // The last wave to drain puts the two counters back to zero for the next launch on this scratch, which
-  // saves a fill dispatch per solve (a dispatch that would queue behind the resident waves of other streams).
-  // A wave counts itself done only after it saw the problem counter run out, so nobody pulls after the reset.
-  if (lane == 63) {
-    __threadfence();
-    const unsigned done = atomicAdd(a.counter + 1, 1u);
-    if (done == gridDim.x - 1) {
-      __threadfence();
-      a.counter[0] = 0u;
-      a.counter[1] = 0u;
-    }
-  }
+  // Every group leaves the loop after exactly one failing pull, so the counter ends at base + B + NG.
 }
 
 }  // namespace alilqr

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ALILQR_ABI_VERSION 2
+#define ALILQR_ABI_VERSION 3
 
 /* ---- vehicle model (node type) ------------------------------------------
  * LAT      4 states / 1 control   cilqr/lat_bicycle_node.py:4-91
@@ -163,8 +163,9 @@ int64_t alilqr_workspace_bytes(const alilqr_problem* p);
  *       status [B][ALILQR_STATUS_WORDS]   (may be NULL)
  *  stream      hipStream_t to enqueue on (NULL = default stream); the call
  *              returns after enqueueing, outputs are valid once the stream drains.
- *              Every stream (up to 8 per device) gets its own scratch, so solves on different streams
- *              may overlap on the GPU; solves on one stream run in order.
+ *              Scratch comes from a pool of the library (grown with hipMalloc on first use of a size): solves
+ *              on different streams get different scratch and may overlap on the GPU, solves on one stream
+ *              run in order; any number of streams may be used.
  * Returns ALILQR_OK or a negative alilqr_status; never throws.
  */
 int32_t alilqr_solve_batch(const alilqr_problem* p,
@@ -278,8 +279,17 @@ int32_t alilqr_node_aux_batch(const alilqr_problem* p,
                               double* cval, double* lam_new, double* viol, double* par_cost, double* fxx,
                               void* stream);
 
-/* Release every cached device workspace of the calling process. */
+/* Release every cached device workspace of the calling process (waits for the solves in flight). */
 int32_t alilqr_release(void);
+
+/*
+ * Tuning / diagnostic overrides of the whole process (no counterpart in the reference); 0 = automatic.
+ *   lanes      lanes per problem (1, 4, 8, 16, 32)
+ *   max_waves  upper bound of resident waves per solve
+ *   no_lds     1: keep the linearisation records in HBM even where they fit in LDS
+ * Results do not depend on any of them (tests compare the bits).
+ */
+int32_t alilqr_set_tuning(int32_t lanes, int32_t max_waves, int32_t no_lds);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture
+def tuning():
+    """Setter of the library's tuning overrides (lanes per problem, resident waves, LDS use); automatic again afterwards."""
+    from ilqr_amd import capi
+
+    def set_(**kw):
+        capi.set_tuning(**kw)
+
+    yield set_
+    capi.set_tuning()
+
+
 def _gpu_present():
     try:
         import torch

@@ -105,11 +105,11 @@ def test_multi_start_matches_oracle_and_picks_the_same_winner(mode):
 
 @pytest.mark.parametrize("name", ["lat_rect_demo", "kin_rect_config3"])
 @pytest.mark.parametrize("lanes", ["auto", "1", "8"])
-def test_rectangle_obstacle_activation_matches_oracle(name, lanes, monkeypatch):
+def test_rectangle_obstacle_activation_matches_oracle(name, lanes, tuning):
     """Row activation by rectangle obstacles (new_al_ilqr.h:525-625): the reference's lateral demo and benchmark
     configuration 3 (kinematic model + linear table + rectangles)."""
     if lanes != "auto":
-        monkeypatch.setenv("ALILQR_LANES", lanes)
+        tuning(lanes=int(lanes))
     prob, kw = (problems.new_al_lat_rect(32) if name == "lat_rect_demo" else problems.kin_rect(32))
     ref = ol.solve_batch(*prob, **kw)
     o = to_np(batch.solve_batch(*prob, **kw))

@@ -52,9 +52,9 @@ FLOOR = {"box6": 0.8, "box6_h30": 0.8, "lat4": 0.8, "box6_active_bound": 0.25, "
 
 @pytest.mark.parametrize("lanes", ["auto", "1", "4", "32"])
 @pytest.mark.parametrize("name", list(SETS))
-def test_new_al_matches_oracle(name, lanes, monkeypatch):
+def test_new_al_matches_oracle(name, lanes, tuning):
     if lanes != "auto":
-        monkeypatch.setenv("ALILQR_LANES", lanes)
+        tuning(lanes=int(lanes))
     B = 48
     desc, x0, goals, Q, R, cons = SETS[name](B)
     ref = ol.solve_batch(desc, x0, goals, Q, R, cons)
@@ -75,11 +75,11 @@ def test_new_al_matches_oracle(name, lanes, monkeypatch):
     assert np.all(o["viol"][conv] < desc.prm.viol_stop)
 
 
-def test_new_al_lane_width_does_not_change_bits(monkeypatch):
+def test_new_al_lane_width_does_not_change_bits(tuning):
     desc, x0, goals, Q, R, cons = problems.new_al_box(32, H=30, seed=9)
     outs = []
     for g in ("1", "4", "8", "16", "32"):
-        monkeypatch.setenv("ALILQR_LANES", g)
+        tuning(lanes=int(g))
         outs.append(to_np(batch.solve_batch(desc, x0, goals, Q, R, cons)))
     for o in outs[1:]:
         for k in ("x", "u", "cost", "status", "lam", "mu"):

@@ -46,8 +46,8 @@ def oracle_stable_mask(desc, x0, goals, Q, R, cons, ref, probes=3):
 
 
 @pytest.fixture(params=["1", "8", "32"])
-def lanes(request, monkeypatch):
-    monkeypatch.setenv("ALILQR_LANES", request.param)
+def lanes(request, tuning):
+    tuning(lanes=int(request.param))
     return int(request.param)
 
 
@@ -135,11 +135,11 @@ def test_size_independent_properties_at_full_size():
     assert np.all(a["status"][:, 0] >= 1) and np.all(a["status"][:, 1] <= desc.prm.max_outer)
 
 
-def test_lane_group_width_does_not_change_results(monkeypatch):
+def test_lane_group_width_does_not_change_results(tuning):
     desc, x0, goals, Q, R, cons = problems.lat_legacy(257, 50, seed=3)
     outs = []
     for g in ("1", "4", "16", "32"):
-        monkeypatch.setenv("ALILQR_LANES", g)
+        tuning(lanes=int(g))
         outs.append(to_np(batch.solve_batch(desc, x0, goals, Q, R, cons)))
     for o in outs[1:]:
         for k in o:
@@ -158,13 +158,12 @@ def test_empty_and_ragged_batches(B, lanes):
             assert worst_err(o, ref, i) < TOL
 
 
-def test_persistent_groups_drain_a_batch_larger_than_the_grid(monkeypatch):
+def test_persistent_groups_drain_a_batch_larger_than_the_grid(tuning):
     """Fewer resident groups than problems: every problem is still solved exactly once."""
-    monkeypatch.setenv("ALILQR_LANES", "32")
-    monkeypatch.setenv("ALILQR_MAX_WAVES", "8")       # 16 groups for 100 problems
+    tuning(lanes=32, max_waves=8)                     # 16 groups for 100 problems
     desc, x0, goals, Q, R, cons = problems.lat_legacy(100, 50, seed=9)
     o = to_np(batch.solve_batch(desc, x0, goals, Q, R, cons))
-    monkeypatch.delenv("ALILQR_MAX_WAVES")
+    tuning(lanes=32)
     full = to_np(batch.solve_batch(desc, x0, goals, Q, R, cons))
     for k in o:
         assert np.array_equal(o[k], full[k], equal_nan=True), k
@@ -264,15 +263,15 @@ def test_node_aux_kernel_matches_reference_vectors(tag, model, mode):
         assert gu.rel_err(o["viol"][:, 0], k[pre + "viol"]) < 1e-12
 
 
-def test_lds_resident_linearisation_records_do_not_change_bits(monkeypatch):
-    """The 32-lane LEGACY kernels keep their linearisation records in LDS where they fit; ALILQR_NO_LDS=1 forces
+def test_lds_resident_linearisation_records_do_not_change_bits(tuning):
+    """The 32-lane LEGACY kernels keep their linearisation records in LDS where they fit; the no_lds tuning override forces
     the HBM path.  Same arithmetic, same bits."""
     outs = []
     for prob in (problems.lat_legacy(96, 50, seed=31), problems.full_legacy("dyn", 48, 60, 32)):
-        monkeypatch.delenv("ALILQR_NO_LDS", raising=False)
+        tuning(no_lds=0)
         a = to_np(batch.solve_batch(*prob))
-        monkeypatch.setenv("ALILQR_NO_LDS", "1")
+        tuning(no_lds=1)
         b = to_np(batch.solve_batch(*prob))
-        monkeypatch.delenv("ALILQR_NO_LDS", raising=False)
+        tuning(no_lds=0)
         for k in ("x", "u", "cost", "status", "lam"):
             assert np.array_equal(a[k], b[k], equal_nan=True), k

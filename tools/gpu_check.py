@@ -7,6 +7,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import golden_util as gu, oracle_lib as ol
 from ilqr_amd import batch
 
+from ilqr_amd import capi as _capi
+_capi.set_tuning(lanes=int(os.environ.get("ALILQR_LANES", "0") or 0))   # development switch of this script
+
 def main():
     sets = sys.argv[1:] or ["lat_legacy", "dyn_legacy", "kin_legacy", "fast_box", "fast_linear"]
     for name in sets:

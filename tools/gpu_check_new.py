@@ -7,6 +7,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import golden_util as gu, oracle_lib as ol
 from ilqr_amd import problems
 
+from ilqr_amd import capi as _capi
+_capi.set_tuning(lanes=int(os.environ.get("ALILQR_LANES", "0") or 0))   # development switch of this script
+
 def sets(B):
     return {"new_box": problems.new_al_box(B), "new_box_active": problems.new_al_box(B, y_max=20.0),
             "new_lat": problems.new_al_lat(B), "new_box_h30": problems.new_al_box(B, H=30, seed=9)}

@@ -26,6 +26,7 @@ def main():
     from ilqr_amd import capi, batch, problems
     capi.LIB_PATH = path
     lib = capi.load_library()
+    capi.set_tuning(lanes=int(os.environ.get("ALILQR_LANES", "0") or 0))   # development switch of this script
     import torch
     B = int(os.environ.get("B", "4096"))
     workloads = {"lat_legacy": lambda: problems.lat_legacy(B, 50, seed=0),

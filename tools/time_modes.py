@@ -7,6 +7,9 @@ import numpy as np
 import torch
 from ilqr_amd import batch, problems
 
+from ilqr_amd import capi as _capi
+_capi.set_tuning(lanes=int(os.environ.get("ALILQR_LANES", "0") or 0))   # development switch of this script
+
 def main():
     B = int(os.environ.get("B", "4096"))
     sets = {
