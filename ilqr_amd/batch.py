@@ -108,10 +108,12 @@ class BatchSolver:
             self.out.update(node_x=torch.empty((B, H + 1, n), **f64), node_u=torch.empty((B, H, m), **f64),
                             viol=torch.empty((B,), **f64), mu=torch.empty((B,), **f64))
 
-    def run(self, stream_ptr=None):
+    def run(self, stream_ptr=None, noalloc=False):
+        """Enqueue one solve.  ``noalloc`` takes the entry point that works in the library's static scratch and
+        never allocates (solves that overlap on one GPU must then not use it at the same time)."""
         torch = _torch()
         o = self.out
-        fn = self.lib.alilqr_solve_batch
+        fn = self.lib.alilqr_solve_batch_noalloc if noalloc else self.lib.alilqr_solve_batch
         # the library launches on the device that is current on the calling thread
         with torch.cuda.device(self.dev):
             if stream_ptr is None:
@@ -120,7 +122,7 @@ class BatchSolver:
                     _ptr(o["x"]), _ptr(o["u"]), _ptr(o.get("node_x")), _ptr(o.get("node_u")),
                     None, None, _ptr(o["cost"]), _ptr(o.get("viol")), None, _ptr(o.get("mu")),
                     _ptr(o["status"]), C.c_void_p(stream_ptr))
-        capi.check(rc, "alilqr_solve_batch")
+        capi.check(rc, "alilqr_solve_batch_noalloc" if noalloc else "alilqr_solve_batch")
         return o
 
 

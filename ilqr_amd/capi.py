@@ -131,7 +131,7 @@ LIB_PATH = os.environ.get("ALILQR_LIB") or os.path.join(os.path.dirname(os.path.
 EXPORTS = ("alilqr_abi_version", "alilqr_last_error", "alilqr_device_count", "alilqr_default_params",
            "alilqr_workspace_bytes", "alilqr_solve_batch", "alilqr_solve_batch_multistart", "alilqr_solve_batch_ex",
            "alilqr_linearize_batch", "alilqr_node_aux_batch",
-           "alilqr_release", "alilqr_set_tuning")
+           "alilqr_release", "alilqr_solve_batch_noalloc", "alilqr_static_scratch_bytes", "alilqr_set_tuning")
 
 
 class LibraryMissing(RuntimeError):
@@ -171,6 +171,9 @@ def load_library():
     lib.alilqr_node_aux_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 14
     lib.alilqr_linearize_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17
     lib.alilqr_release.restype = C.c_int32
+    lib.alilqr_solve_batch_noalloc.restype = C.c_int32
+    lib.alilqr_solve_batch_noalloc.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17
+    lib.alilqr_static_scratch_bytes.restype = C.c_int64
     lib.alilqr_set_tuning.restype = C.c_int32
     lib.alilqr_set_tuning.argtypes = [C.c_int32] * 3
     if lib.alilqr_abi_version() != ABI_VERSION:

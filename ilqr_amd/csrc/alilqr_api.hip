@@ -68,6 +68,18 @@ std::mutex g_mu;
 // Tuning overrides (alilqr_set_tuning): 0 = automatic.
 std::atomic<int> g_opt_lanes{0}, g_opt_max_waves{0}, g_opt_no_lds{0};
 
+// ---- scratch of the entry point that allocates nothing ----------------------------------------------------------
+// A file-scope device array: every GPU the library runs on holds its own copy until the process ends.  Host code
+// never uses the array's name as an address; the per-device address comes from hipGetSymbolAddress (static_scratch()).
+constexpr size_t kStaticScratchBytes = (size_t)ALILQR_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+struct StaticScratch {
+  void* ptr = nullptr;            // device address of `scratch` on this device
+  bool zeroed = false;            // its counter block has been cleared once
+  unsigned counter_next = 0;
+};
+StaticScratch g_static[kMaxDev];
+
 struct Dims {
   int N, M, NA, NB, E;
 };
@@ -383,6 +395,19 @@ int32_t alilqr_solve_batch_multistart(const alilqr_problem* p,
                                cost, viol, lam, mu, status, stream);
 }
 
+// Address of the static scratch on the current device (once per device, with that device current).
+static int32_t static_scratch(int dev, StaticScratch** out) {
+  StaticScratch& ss = g_static[dev];
+  if (!ss.ptr) {
+    void* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) { set_err("hipGetSymbolAddress(scratch): %s", hipGetErrorString(e)); return ALILQR_E_HIP; }
+    ss.ptr = ptr;
+  }
+  *out = &ss;
+  return ALILQR_OK;
+}
+
 // Take a scratch slot of the pool for a solve of `bytes` on stream `st` (pool lock held by the caller).
 static int32_t take_slot(int dev, hipStream_t st, size_t bytes, Slot** out) {
   Slot* pool = g_slots[dev];
@@ -426,7 +451,7 @@ static int32_t solve_impl(const alilqr_problem* p,
                           double* x_init, double* u_init,
                           double* cost, double* viol,
                           double* lam, double* mu,
-                          int32_t* status, void* stream) {
+                          int32_t* status, void* stream, bool use_static) {
   const double* u_offset = ex ? ex->u_offset : nullptr;
   const int n_left = ex ? ex->n_left : 0, n_right = ex ? ex->n_right : 0;
   const bool rect = (n_left > 0) || (n_right > 0);
@@ -452,14 +477,29 @@ static int32_t solve_impl(const alilqr_problem* p,
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDev) { set_err("device index out of range"); return ALILQR_E_ARG; }
   hipStream_t st = (hipStream_t)stream;
-  Plan pl = make_plan(p, d, rect);
+  Plan pl = make_plan(p, d, rect, use_static ? kStaticScratchBytes : 0);
+  if (pl.total == 0) {
+    set_err("the scratch of one wave of this problem exceeds the static scratch (ALILQR_STATIC_SCRATCH_BYTES)");
+    return ALILQR_E_NOMEM;
+  }
 
   // The pool lock is held until the kernel is enqueued: nothing can free or re-assign the scratch in between.
   std::lock_guard<std::mutex> lk(g_mu);
   char* base = nullptr;
   unsigned* counter_next = nullptr;
   Slot* slot = nullptr;
-  {
+  if (use_static) {
+    StaticScratch* ss = nullptr;
+    rc = static_scratch(dev, &ss);
+    if (rc != ALILQR_OK) return rc;
+    if (!ss->zeroed) {
+      HIP_TRY(hipMemsetAsync(ss->ptr, 0, 256, st));          // counter block, once per device
+      ss->zeroed = true;
+      ss->counter_next = 0;
+    }
+    base = (char*)ss->ptr;
+    counter_next = &ss->counter_next;
+  } else {
     rc = take_slot(dev, st, pl.total, &slot);
     if (rc != ALILQR_OK) return rc;
     base = (char*)slot->ptr;
@@ -522,8 +562,23 @@ int32_t alilqr_solve_batch_ex(const alilqr_problem* p,
                               double* lam, double* mu,
                               int32_t* status, void* stream) {
   return solve_impl(p, x0, goals, Q, R, cons, ex, x_out, u_out, node_x, node_u, x_init, u_init,
-                    cost, viol, lam, mu, status, stream);
+                    cost, viol, lam, mu, status, stream, false);
 }
+
+int32_t alilqr_solve_batch_noalloc(const alilqr_problem* p,
+                                   const double* x0, const double* goals,
+                                   const double* Q, const double* R, const double* cons,
+                                   double* x_out, double* u_out,
+                                   double* node_x, double* node_u,
+                                   double* x_init, double* u_init,
+                                   double* cost, double* viol,
+                                   double* lam, double* mu,
+                                   int32_t* status, void* stream) {
+  return solve_impl(p, x0, goals, Q, R, cons, nullptr, x_out, u_out, node_x, node_u, x_init, u_init,
+                    cost, viol, lam, mu, status, stream, true);
+}
+
+int64_t alilqr_static_scratch_bytes(void) { return (int64_t)kStaticScratchBytes; }
 
 int32_t alilqr_set_tuning(int32_t lanes, int32_t max_waves, int32_t no_lds) {
   if (!(lanes == 0 || lanes == 1 || lanes == 4 || lanes == 8 || lanes == 16 || lanes == 32)) {

@@ -283,6 +283,32 @@ int32_t alilqr_node_aux_batch(const alilqr_problem* p,
 int32_t alilqr_release(void);
 
 /*
+ * alilqr_solve_batch for callers that cannot allocate: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Arguments and results are those of
+ * alilqr_solve_batch (bit-identical outputs); the scratch is a static device array of
+ * ALILQR_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends, and the call makes
+ * no hipMalloc / hipFree.  The solve keeps as many problems resident as fit into that array (the others are
+ * pulled as resident ones finish), so any batch size is accepted; ALILQR_E_NOMEM is returned only when the scratch
+ * of a single wave (a very long horizon) exceeds the array.  All calls on one GPU share the array: calls that
+ * overlap on one GPU (different streams, or threads) race - enqueue them on one stream.  The first call on a
+ * device looks the array's address up and clears its counter block (one hipMemsetAsync): make that call outside
+ * graph capture.  A captured launch cannot be replayed (the kernel arguments carry the counter position).
+ */
+#define ALILQR_STATIC_SCRATCH_BYTES (128u << 20)
+int32_t alilqr_solve_batch_noalloc(const alilqr_problem* p,
+                                   const double* x0, const double* goals,
+                                   const double* Q, const double* R, const double* cons,
+                                   double* x_out, double* u_out,
+                                   double* node_x, double* node_u,
+                                   double* x_init, double* u_init,
+                                   double* cost, double* viol,
+                                   double* lam, double* mu,
+                                   int32_t* status, void* stream);
+
+/* Size of the static scratch of alilqr_solve_batch_noalloc, in bytes (no counterpart in the reference). */
+int64_t alilqr_static_scratch_bytes(void);
+
+/*
  * Tuning / diagnostic overrides of the whole process (no counterpart in the reference); 0 = automatic.
  *   lanes      lanes per problem (1, 4, 8, 16, 32)
  *   max_waves  upper bound of resident waves per solve
