@@ -201,13 +201,21 @@ Plan make_plan(const alilqr_problem* p, const Dims& d, bool rect = false, size_t
   const size_t H = p->horizon, N = d.N, M = d.M;
   const size_t T = (H + 1) * N + H * M;
   const size_t SS = (p->mode == ALILQR_MODE_LEGACY) ? alilqr::TrjSlots<ALILQR_MODE_LEGACY>::SS : alilqr::TrjSlots<ALILQR_MODE_FAST>::SS;
+  // LEGACY: one column of accumulated controls per open-loop line-search trial (2 .. ntrials; the kernel counts
+  // its trials the same way: alpha = 1, 1/2, ... while alpha > alpha_min, at most 64)
+  size_t ucols = 0;
+  if (p->mode == ALILQR_MODE_LEGACY) {
+    int ntrials = 0;
+    for (double al = 1.0; al > p->prm.alpha_min && ntrials < 64; al = al / 2.0) ++ntrials;
+    ucols = ntrials > 1 ? (size_t)(ntrials - 1) : 1;
+  }
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   auto lay = [&](long w) {
     pl.NG = (int)(w * gpw);
     size_t off = 0;
     pl.counter = off; off = up(off + 256);
     pl.trj = off; off = up(off + sizeof(double) * 2 * T * (size_t)pl.NG * SS);
-    pl.ucum = off; off = up(off + sizeof(double) * H * M * (size_t)pl.NG * pl.G);
+    pl.ucum = off; off = up(off + sizeof(double) * H * M * (size_t)pl.NG * ucols);
     pl.blk = off; off = up(off + sizeof(double) * block_doubles_for(p, rect) * (size_t)pl.NG);
     pl.total = off;
   };

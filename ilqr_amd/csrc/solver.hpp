@@ -19,7 +19,7 @@
 // still execute the heavy phases together.
 //
 // Data layout in HBM (fp64).
-//   blk  one block per group: H+1 step records  x_t | u_t | K_t | k_t | goal_t | lambda_t
+//   blk  one block per group: H+1 step records  K_t | k_t | lambda_t
 //        followed by H+1 linearisation records  f_x, f_u entries | l_x | l_u | l_xx | l_uu
 //        (the linearisation records live in LDS instead where they fit at full occupancy).
 //        G > 1: the block is contiguous (problem-major), so a sequential sweep reads one
@@ -28,7 +28,8 @@
 //   trj  candidate trajectories, SS slots per problem and parity, kept only for the trials that usually
 //        win (any other winner is rolled out a second time).  G > 1: [group][2][SS][T], contiguous per
 //        roll-out; G = 1: [2][T][NG*SS], lane-minor.
-//   ucum [H*M][NG*G]   LEGACY: accumulated controls of the open-loop trials, lane-minor.
+//   ucum [group][H*M][trial - 2]   LEGACY: accumulated controls of the open-loop trials 2 .. ntrials; the
+//        lanes of a roll-out pass read one contiguous run per step.
 // The current trajectory of a problem is the pair (slot, parity) of the last
 // accepted roll-out; nothing is copied on acceptance.  Sequential sweeps (P2, P3)
 // load the record of the next step before computing the current one.
@@ -60,6 +61,12 @@ __device__ __forceinline__ ctab as_ctab(const double* p) {
   return (ctab)p;
 #pragma clang diagnostic pop
 }
+
+#ifdef ALILQR_LIT_LAT
+__constant__ const double kLitQ[16] = {1e-3, 0, 0, 0, 0, 1e-1, 0, 0, 0, 0, 1e1, 0, 0, 0, 0, 1e-9};
+__constant__ const double kLitR[1] = {50.0};
+__constant__ const double kLitB[10] = {-1000, -1000, -2 * 3.141592653589793, -10.0, 1000, 1000, 2 * 3.141592653589793, 10.0, -0.1, 0.1};
+#endif
 
 struct KArgs {
   int B, NG, H, C, goal_batch, table_nodes;
@@ -795,14 +802,14 @@ struct NodeOps<MODEL, kModeNewAlQuadRect> : NewAlOps<MODEL, true, true> {};
 // the kernel
 // ---------------------------------------------------------------------------
 // Per-step record of a problem, contiguous in the group's block:
-//   x_t | u_t | K_t | k_t | goal_t | lambda_t        (RecLayout)
+//   K_t | k_t | lambda_t        (RecLayout; x_t, u_t are read from the current trajectory, goals from the input)
 // followed (after all H+1 records) by the per-node linearisation records:
 //   LEGACY  f_x entries | f_u entries | l_x | l_u | diagonal AL terms of l_xx | of l_uu
 //   FAST    f_x entries | f_u entries | l_x | l_u | l_xx (N x N) | l_uu (M x M)
 template <class MD>
 struct RecLayout {
   static constexpr int N = MD::N, M = MD::M;
-  static constexpr int rx = 0, ru = rx + N, rK = ru + M, rk = rK + M * N, rg = rk + M, rl = rg + N;
+  static constexpr int rK = 0, rk = rK + M * N, rl = rk + M;
 };
 template <class MD, int MODE>
 struct NodeRec {
@@ -815,7 +822,7 @@ struct NodeRec {
 };
 
 // doubles of one group's block (host and device must agree)
-// doubles of one step record: x | u | K | k | goal | lambda[C] (| overlay: sign[C] | C'[C] | row index)
+// doubles of one step record: K | k | lambda[C] (| overlay: sign[C] | C'[C] | row index)
 template <class MD, int MODE>
 __host__ __device__ constexpr int record_doubles(int C) {
   return (RecLayout<MD>::rl + C + (is_rect(MODE) ? 2 * C + 1 : 0) + 1) & ~1;
@@ -826,6 +833,9 @@ __host__ __device__ inline size_t block_doubles(int H, int C) {
   return (size_t)(H + 1) * (RS + NodeRec<MD, MODE>::E);
 }
 
+#ifndef ALILQR_LEAN_LOADS
+#define ALILQR_LEAN_LOADS 0   // 1: a roll-out lane loads the reference point / gains / multipliers of a node only when its trial needs them (measured slower: divergent loads, more spills)
+#endif
 #ifndef ALILQR_TRIP_N6
 #define ALILQR_TRIP_N6 0   // per-trip passes for the 6-state kernels too (measured slower: their register allocation suffers)
 #endif
@@ -866,7 +876,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
   // need different numbers of passes); with two groups per wave the passes of a line search run back to back,
   // which also keeps the register allocation of the 6-state kernels tight.
   constexpr bool TRIP = (G < 32) && (N <= 4 || ALILQR_TRIP_N6);
-  constexpr bool PM = (G > 1);                         // block layout: problem-major (contiguous) or element-major
+  constexpr bool PM = true;                            // block layout: problem-major (one contiguous block per group)
   constexpr int CL = LEGACY ? (MD::CTRL_ROWS ? 2 * (N + M) : 2 * N) : 1;         // multipliers held in registers (LEGACY only)
   constexpr int SS = TrjSlots<MODE>::SS;               // trajectory slots kept per problem and parity
 
@@ -923,6 +933,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
   int p = -1;                 // problem being solved, -1: none
   bool drained = false;       // the batch counter ran out
   int cur_slot = 0, cur_par = 0;
+  int ref_slot = 0;           // slot of the trajectory the running line search started from (cur_slot moves to the winner before a repeat)
   double mu = 1.0, old_cost = 0.0, viol = 0.0, dv_lin = 0.0;
   int outer = 0, inner = 0, n_inner = 0, n_trials = 0;
   bool outer_start = false;
@@ -937,7 +948,11 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
   double new_cost = 0.0, J_last = 0.0, replay_alpha = 0.0, bestJ = 0.0, bestA = 0.0;
   bool keep_old = false, gate_skip = false, have = false;
   int win_trial = -1, win_lane = -1, r0 = 0, replay_kind = 0;
-  size_t replay_ul = 0;
+  // LEGACY: bit t set = some multiplier of node t is not zero (nodes 0 .. 127; longer horizons load them always).
+  // A roll-out step reads the node's multipliers only then: they are all zero during the first outer iteration
+  // and on most nodes later.
+  unsigned long long lmask0 = 0ull, lmask1 = 0ull;
+  const bool lam_all = (H + 1 > 128);
 
   // candidate trajectories.  G > 1: [group][parity][slot][element], a lane writes its roll-out as one contiguous
   // run and a node's (x, u) is one short run; G = 1: [parity][element][group * SS + slot], lane-minor, so the
@@ -946,14 +961,20 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
     if (PM) return trj + ((gid * 2 + par) * SS + slot) * (size_t)T + off;
     return trj + ((size_t)par * T + off) * (NG * SS) + gid * SS + slot;
   };
-  // accumulated controls of the LEGACY open-loop trials: [t * M + r][global lane]
-  auto ucum_at = [&](int off, size_t lane_global) -> double* { return a.ucum + (size_t)off * LT + lane_global; };
   auto rec = [&](int t) -> double* { return blk + (size_t)t * RS * ES; };
   auto lrec = [&](int t) -> double* { return linb + (size_t)t * NR::E * ES; };
+#ifdef ALILQR_LIT_LAT   /* timing experiment only: the tables of the headline problem as literals */
+  auto tabQ = [&](int) { return (ctab)kLitQ; };
+  auto tabR = [&](int) { return (ctab)kLitR; };
+  auto tabC = [&](int) { return (ctab)kLitB; };
+#else
   auto tabQ = [&](int t) { return as_ctab(a.Q) + (size_t)((a.table_nodes > 1) ? t : 0) * N * N; };
   auto tabR = [&](int t) { return as_ctab(a.R) + (size_t)((a.table_nodes > 1) ? t : 0) * M * M; };
   auto tabC = [&](int t) { return as_ctab(a.cons) + (size_t)((a.table_nodes > 1) ? t : 0) * cw; };
+#endif
 
+  // goal list of problem q (clamped: idle groups still form addresses)
+  auto goal_of = [&](int q) -> const double* { return a.goals + ((a.goal_batch > 1 && q > 0) ? (size_t)q * XS : 0); };
   // node t of the current trajectory (slot of the last accepted roll-out)
   auto load_node = [&](int t, double* x, double* u) {
 #pragma unroll
@@ -966,7 +987,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
     const double* r = rec(t);
     double g[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) g[i] = r[(size_t)(RL::rg + i) * ES];
+    for (int i = 0; i < N; ++i) g[i] = goal_of(p)[(size_t)t * N + i];
     if (LEGACY) {
       double lam[CL];
 #pragma unroll
@@ -1005,11 +1026,10 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
       } else {
         p = np;
         const double* goals = a.goals + ((a.goal_batch > 1) ? (size_t)p * XS : 0);
-        // goals and zero multipliers into the records, lanes in parallel
+        // zero multipliers into the records, lanes in parallel
+        lmask0 = 0ull; lmask1 = 0ull;
         for (int t = gl; t <= H; t += G) {
           double* r = rec(t);
-#pragma unroll
-          for (int i = 0; i < N; ++i) r[(size_t)(RL::rg + i) * ES] = goals[(size_t)t * N + i];
           for (int i = 0; i < C; ++i) r[(size_t)(RL::rl + i) * ES] = 0.0;
           if (RECT) {
             for (int i = 0; i < 2 * C; ++i) r[(size_t)(RL::rl + C + i) * ES] = 0.0;
@@ -1146,8 +1166,8 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
     // every group of the wave idle and nothing left to pull: done
     if (__ballot(p >= 0) == 0ull) break;
 
-    if (p >= 0) {
-     if (phase == PH_LIN) {
+    if (p >= 0 && phase == PH_LIN) {
+     {
       // ================= outer-iteration start: J under the current multipliers =================
       bool tables_changed = false;
       if (RECT) {
@@ -1205,6 +1225,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
         outer_start = false;
       }
       np_ = 1 - cur_par;
+      ref_slot = cur_slot;
 
       PROF_MARK(1)
       // ================= P1: linearise + quadratise, parallel in time =================
@@ -1214,9 +1235,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
         double* r = rec(t);
         double* lr = lrec(t);
 #pragma unroll
-        for (int i = 0; i < N; ++i) { r[(size_t)(RL::rx + i) * ES] = x[i]; g[i] = r[(size_t)(RL::rg + i) * ES]; }
-#pragma unroll
-        for (int j = 0; j < M; ++j) r[(size_t)(RL::ru + j) * ES] = u[j];
+        for (int i = 0; i < N; ++i) g[i] = goal_of(p)[(size_t)t * N + i];
         if (t < H) {
           double ac[MD::NA], bc[MD::NB];
           MD::template jac<!NEWAL>(mc, x, u, ac, bc);
@@ -1349,27 +1368,48 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
       gate_skip = NEWAL && (fabs(dv_lin) < a.prm.dv_gate);      // new_al_ilqr.h:1039
       stage = gate_skip ? ST_DONE : ST_TRIALS;
       r0 = 0;                                    // first trial of the current round, or first ladder column
-      replay_kind = 0; replay_alpha = 0.0; bestJ = 0.0; bestA = 0.0; replay_ul = 0; have = false;
+      replay_kind = 0; replay_alpha = 0.0; bestJ = 0.0; bestA = 0.0; have = false;
       phase = PH_ROLL;
      }
 
+    }
       PROF_MARK(3)
       // ================= P3: roll-outs, one line-search trial per lane =================
+      // What a roll-out reads and writes of a problem: the group's block (step records), the trajectory slots
+      // of the parity being written, the penalty.  A lane normally works for its own group; in the compacted
+      // passes of the LEGACY line search it works for whichever group of the wave still has trials to run.
+      //   blk   the group's block (K, k, multipliers per node)        cur   its current trajectory (x | u)
+      //   trjp  the trajectory slots of the parity being written       goal  its goal list
+      //   lm0/1 which nodes carry a multiplier that is not zero (LEGACY)
+      struct Tgt { double* blk; double* trjp; const double* cur; const double* goal; double mu; unsigned long long lm0, lm1; };
       struct RecRegs { double x[N], u[M], K[M][N], k[M], g[N], lam[CL]; };
-      auto load_rec = [&](int t, RecRegs& R) {
-        const double* r = rec(t);
+      // A lane loads what its trial needs of node t: the goal (through scalar loads when all problems share one
+      // goal list), the reference point and the gains only for a closed-loop trial, the multipliers only where
+      // the node has any.  The open-loop trials of the LEGACY line search (all but the first) need neither.
+      auto load_rec = [&](const Tgt& tg, int t, RecRegs& R, bool closed) {
+        const double* r = tg.blk + (size_t)t * RS * ES;
 #pragma unroll
-        for (int i = 0; i < N; ++i) { R.x[i] = r[(size_t)(RL::rx + i) * ES]; R.g[i] = r[(size_t)(RL::rg + i) * ES]; }
+        for (int i = 0; i < N; ++i) R.g[i] = tg.goal[(size_t)t * N + i];
+        if (!LEGACY || closed || !ALILQR_LEAN_LOADS) {
 #pragma unroll
-        for (int j = 0; j < M; ++j) {
-          R.u[j] = r[(size_t)(RL::ru + j) * ES];
-          R.k[j] = r[(size_t)(RL::rk + j) * ES];
+          for (int i = 0; i < N; ++i) R.x[i] = tg.cur[(size_t)t * N + i];
 #pragma unroll
-          for (int i = 0; i < N; ++i) R.K[j][i] = r[(size_t)(RL::rK + j * N + i) * ES];
+          for (int j = 0; j < M; ++j) {
+            R.u[j] = (t < H) ? tg.cur[(size_t)XS + (size_t)t * M + j] : 0.0;
+            R.k[j] = r[(size_t)(RL::rk + j) * ES];
+#pragma unroll
+            for (int i = 0; i < N; ++i) R.K[j][i] = r[(size_t)(RL::rK + j * N + i) * ES];
+          }
         }
         if (LEGACY) {
+          const bool lam_on = !ALILQR_LEAN_LOADS || lam_all || (((t < 64 ? tg.lm0 >> t : tg.lm1 >> (t - 64)) & 1ull) != 0ull);
+          if (lam_on) {
 #pragma unroll
-          for (int i = 0; i < CL; ++i) R.lam[i] = r[(size_t)(RL::rl + i) * ES];
+            for (int i = 0; i < CL; ++i) R.lam[i] = r[(size_t)(RL::rl + i) * ES];
+          } else {
+#pragma unroll
+            for (int i = 0; i < CL; ++i) R.lam[i] = 0.0;
+          }
         }
       };
       // Only the trials that usually win keep their trajectory (LEGACY: 1, 2 and the last one, which the
@@ -1382,24 +1422,28 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
       // roll out one trial.  kind 0: closed loop, step alpha (Python generations: (u + alpha k) + K dx;
       // C++ generation: u + (K dx + alpha k)); kind 1: LEGACY open loop on the accumulated controls of
       // lane `ul`; kind 2: one column of the C++ generation's five-wide ladder (no angle wrap, (u + K dx) + k alpha)
-      auto rollout = [&](bool valid, int kind, double alpha, size_t ul, int sslot) -> double {
+      auto rollout = [&](const Tgt& tg, bool valid, int kind, double alpha, const double* ucol, size_t ucs, int sslot) -> double {
         double J = 0.0;
         double x[N];
+        const double mu = tg.mu;                       // shadows the group's own penalty
+        double* const tout = tg.trjp + (size_t)(sslot >= 0 ? sslot : 0) * T;
+        auto rec = [&](int t) -> double* { return tg.blk + (size_t)t * RS * ES; };
+        const bool closed = !(LEGACY && kind == 1);
         RecRegs RA, RB;
-        load_rec(0, RA);
+        load_rec(tg, 0, RA, closed);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-          x[i] = RA.x[i];
-          if (valid && sslot >= 0) *trj_at(np_, i, sslot) = x[i];
+          x[i] = tg.cur[i];
+          if (valid && sslot >= 0) tout[i] = x[i];
         }
         double uown[M];
 #pragma unroll
-        for (int r = 0; r < M; ++r) uown[r] = (LEGACY && kind == 1) ? *ucum_at(r, ul) : 0.0;
+        for (int r = 0; r < M; ++r) uown[r] = (LEGACY && kind == 1 && valid) ? ucol[(size_t)r * ucs] : 0.0;
         auto roll = [&](int t, const RecRegs& R, RecRegs& Rn) {
-          load_rec(t + 1, Rn);                         // next record in flight while this step computes
+          load_rec(tg, t + 1, Rn, closed);             // next record in flight while this step computes
           double unext[M];
 #pragma unroll
-          for (int r = 0; r < M; ++r) unext[r] = (LEGACY && kind == 1 && t + 1 < H) ? *ucum_at((t + 1) * M + r, ul) : 0.0;
+          for (int r = 0; r < M; ++r) unext[r] = (LEGACY && kind == 1 && valid && t + 1 < H) ? ucol[(size_t)((t + 1) * M + r) * ucs] : 0.0;
           double u[M];
           if (LEGACY && kind == 1) {
 #pragma unroll
@@ -1432,9 +1476,9 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
             }
             if (sslot >= 0) {
 #pragma unroll
-              for (int r = 0; r < M; ++r) *trj_at(np_, XS + t * M + r, sslot) = u[r];
+              for (int r = 0; r < M; ++r) tout[XS + t * M + r] = u[r];
 #pragma unroll
-              for (int i = 0; i < N; ++i) *trj_at(np_, (t + 1) * N + i, sslot) = xn[i];
+              for (int i = 0; i < N; ++i) tout[(t + 1) * N + i] = xn[i];
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) x[i] = xn[i];
@@ -1476,6 +1520,137 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
         for (int q = 1; q < j && q < 64; ++q) al = al / 2.0;
         return al;
       };
+      if constexpr (LEGACY) {
+        // ---- LEGACY line search, wave-wide.  Trial 1 is the closed-loop step; trials >= 2 run open loop on
+        //      accumulated controls (ilqr.py:119 with new_u aliasing u after the first rejected step).
+        //      Pass A: every group rolls out its first G trials on its own lanes.  Passes B: the trials that are
+        //      left of the groups whose pass A found no acceptable step are spread over ALL 64 lanes of the
+        //      wave, so a narrow group borrows the lanes of the groups that are already done.  The first
+        //      (largest step) accepted trial wins, exactly the sequential rule.  Pass C (rare): a winner whose
+        //      trajectory was not kept is rolled out once more, lane 0 keeps it in the spare slot.
+        //      All passes go through ONE roll-out call site (the code exists once in the instruction cache).
+        const bool act = (p >= 0);
+        const size_t gid0 = gid - (size_t)(lane / G);                    // first group of this wave
+        const size_t UCS = (size_t)(ntrials > 1 ? ntrials - 1 : 1);      // open-loop trials 2 .. ntrials
+        const size_t UC = UCS * US;                                      // accumulated controls of one group
+        double* const ucg = a.ucum + gid * UC;                           // [t * M + r][trial - 2]: a step's controls of all trials are contiguous
+        if (act) {
+          // all accumulated controls, nodes in parallel:  u_j = u_{j-1} + 2^-(j-1) k
+          for (int t = gl; t < H; t += G) {
+            const double* rt = rec(t);
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+              const double kf = rt[(size_t)(RL::rk + r) * ES];
+              double sacc = *trj_at(cur_par, XS + t * M + r, cur_slot);
+              double al = alpha_of(2);
+              for (int i = 2; i <= ntrials; ++i) {
+                sacc = sacc + al * kf;
+                al = al / 2.0;
+                ucg[(size_t)(t * M + r) * UCS + (i - 2)] = sacc;
+              }
+            }
+          }
+        }
+        __threadfence_block();
+        const Tgt own{blk, trj + ((gid * 2 + (size_t)np_) * SS) * (size_t)T, trj_at(cur_par, 0, ref_slot), goal_of(p), mu, lmask0, lmask1};
+        const int R = ntrials - G;                                       // trials left per group after pass A
+        const int nA = (G < ntrials) ? G : ntrials;
+        enum { PASS_A = 0, PASS_B = 1, PASS_C = 2 };
+        int pass = PASS_A, base = 0, total = 0, my_rank = 0, found = -1;
+        unsigned long long nb = 0ull;
+        double foundJ = 0.0, JlastL = 0.0;
+        bool need = false;
+        for (;;) {
+          Tgt tg = own;
+          bool v;
+          int kind, sslot, trial;
+          double oc_t = old_cost;
+          size_t gid_t = gid;
+          if (pass == PASS_A) {
+            trial = gl + 1;
+            v = act && trial <= ntrials;
+          } else if (pass == PASS_B) {
+            const int item = base + lane;
+            v = item < total;
+            const int fr = v ? item / R : 0;
+            trial = G + 1 + (v ? item % R : 0);
+            int ol = 0;                                                  // first lane of the fr-th searching group
+            {
+              unsigned long long m = nb;
+              for (int q = 0; q < fr; ++q) m &= m - 1ull;
+              ol = m ? (__ffsll((long long)m) - 1) : 0;
+            }
+            const double mu_t = __shfl(mu, ol);
+            oc_t = __shfl(old_cost, ol);
+            const int np_t = __shfl(np_, ol), cs_t = __shfl(ref_slot, ol), p_t = __shfl(p, ol);
+            const unsigned long long lm0_t = __shfl(lmask0, ol), lm1_t = __shfl(lmask1, ol);
+            gid_t = gid0 + (size_t)(ol / G);
+            tg = Tgt{a.blk + gid_t * block_doubles<MD, MODE>(H, C), trj + ((gid_t * 2 + (size_t)np_t) * SS) * (size_t)T,
+                     trj + ((gid_t * 2 + (size_t)(1 - np_t)) * SS + (size_t)cs_t) * (size_t)T, goal_of(p_t), mu_t, lm0_t, lm1_t};
+          } else {
+            trial = win_trial;
+            v = act && store_slot(win_trial) < 0;
+          }
+          kind = (trial != 1) ? 1 : 0;
+          sslot = !v ? -1 : (pass == PASS_C) ? ((gl == 0) ? SS - 1 : -1) : store_slot(trial);
+          const double J = rollout(tg, v, kind, 1.0, a.ucum + gid_t * UC + (size_t)(trial >= 2 ? trial - 2 : 0), UCS, sslot);
+          if (pass == PASS_C) break;
+          bool search_over = false;
+          if (pass == PASS_A) {
+            const int w = gfirst<G>(v && (J < old_cost), lane);
+            if (w >= 0) found = w + 1;
+            foundJ = gbcast<G>(J, w >= 0 ? w : 0);
+            JlastL = gbcast<G>(J, nA - 1);                               // the last trial's cost once all have run
+            need = act && found < 0 && R > 0;
+            nb = __ballot(need && gl == 0);                              // first lanes of the groups still searching
+            total = (R > 0) ? __popcll(nb) * R : 0;
+            my_rank = __popcll(nb & ((1ull << (lane & ~(G - 1))) - 1ull));
+            if (total > 0) pass = PASS_B; else search_over = true;
+          } else {
+            const unsigned long long okb = __ballot(v && (J < oc_t));
+            // lanes [lo, hi) of this pass ran my group's trials G+1 .. ntrials
+            const int lo = my_rank * R - base, hi = lo + R;
+            int src_w = lane, src_l = lane, hit_trial = -1;
+            bool has_last = false;
+            if (need && found < 0) {
+              const int l0 = lo < 0 ? 0 : lo, h0 = hi > 64 ? 64 : hi;
+              if (l0 < h0) {
+                const unsigned long long msk = ((h0 - l0 >= 64) ? ~0ull : ((1ull << (h0 - l0)) - 1ull)) << l0;
+                const unsigned long long mm = okb & msk;
+                if (mm) {
+                  const int wl = __ffsll((long long)mm) - 1;
+                  src_w = wl;
+                  hit_trial = G + 1 + (base + wl - my_rank * R);
+                }
+                if (hi >= 1 && hi <= 64) { has_last = true; src_l = hi - 1; }
+              }
+            }
+            const double Jw = __shfl(J, src_w), Jl = __shfl(J, src_l);
+            if (hit_trial >= 0) { found = hit_trial; foundJ = Jw; }
+            if (has_last) JlastL = Jl;
+            base += 64;
+            if (base >= total || __ballot(need && found < 0) == 0ull) search_over = true;
+          }
+          if (search_over) {
+            if (act) {
+              if (found >= 0) {
+                win_trial = found; new_cost = foundJ; n_trials += found;
+              } else {
+                // every step rejected: the reference is left holding the last trial's arrays (ilqr.py:137-147)
+                win_trial = ntrials; new_cost = JlastL; n_trials += ntrials;
+              }
+            }
+            if (__ballot(act && store_slot(win_trial) < 0) == 0ull) break;
+            pass = PASS_C;
+          }
+        }
+        if (act) {
+          const int ws = store_slot(win_trial);
+          cur_slot = (ws < 0) ? SS - 1 : ws;
+          stage = ST_DONE;
+        }
+      } else if (p >= 0) {
+        const Tgt own{blk, trj + ((gid * 2 + (size_t)np_) * SS) * (size_t)T, trj_at(cur_par, 0, ref_slot), goal_of(p), mu, 0ull, 0ull};
       // The passes of the line search (rounds of trials, the C++ generation's ladder, the repeat of a winner
       // whose trajectory was not kept) go through ONE roll-out call: the groups of a wave that are in
       // different passes still execute it together, and the roll-out code exists once.
@@ -1483,34 +1658,11 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
         bool valid = true;
         int kind = 0, sslot = -1;
         double alpha = 1.0;
-        size_t ul = lg;
         if (stage == ST_TRIALS) {
           const int j = r0 + gl + 1;             // trial number, 1-based
           valid = j <= ntrials;
-          kind = (LEGACY && j != 1) ? 1 : 0;     // LEGACY trials >= 2 run open loop on accumulated controls
           alpha = alpha_of(j);
           sslot = valid ? store_slot(j) : -1;
-          if (LEGACY) {
-            // Accumulated controls of the open-loop trials of this round, nodes in parallel:
-            //   u_i = u_{i-1} + 2^-(i-1) k   (ilqr.py:119 with new_u aliasing u); lane i-1-r0 rolls u_i out.
-            const int first = (r0 == 0) ? 2 : r0 + 1;
-            const int last = (r0 + G < ntrials) ? r0 + G : ntrials;
-            const bool from_cur = (r0 == 0) || (G == 1 && r0 == 1);
-            for (int t = gl; t < H && first <= last; t += G) {
-              const double* rt = rec(t);
-#pragma unroll
-              for (int r = 0; r < M; ++r) {
-                const double kf = rt[(size_t)(RL::rk + r) * ES];
-                double sacc = from_cur ? rt[(size_t)(RL::ru + r) * ES] : *ucum_at(t * M + r, gid * G + (G - 1));
-                double al = alpha_of(first);
-                for (int i = first; i <= last; ++i) {
-                  sacc = sacc + al * kf;
-                  al = al / 2.0;
-                  *ucum_at(t * M + r, gid * G + (i - 1 - r0)) = sacc;
-                }
-              }
-            }
-          }
         } else if (stage == ST_LADDER) {
           // five-wide ladder alpha, alpha/3, ... from alpha = 2^-10 (new_al_ilqr.h:818-898)
           const int i = r0 + gl;
@@ -1520,11 +1672,11 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
           for (int q = 0; q < i && q < 5; ++q) alpha /= 3.0;
         } else {
           // every lane of the group repeats the winner's roll-out, lane 0 keeps it in the spare slot
-          kind = replay_kind; alpha = replay_alpha; ul = replay_ul;
+          kind = replay_kind; alpha = replay_alpha;
           sslot = (gl == 0) ? SS - 1 : -1;
         }
         __threadfence_block();
-        const double J = rollout(valid, kind, alpha, ul, sslot);
+        const double J = rollout(own, valid, kind, alpha, nullptr, 0, sslot);
 
         if (stage == ST_TRIALS) {
           const bool ok = valid && (J < old_cost);
@@ -1538,19 +1690,13 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
             n_trials += nv;
             if (r0 + G >= ntrials) {
               J_last = gbcast<G>(J, nv - 1);
-              if (LEGACY) {
-                // every step rejected: the reference is left holding the last trial's arrays (ilqr.py:137-147)
-                win_lane = nv - 1; win_trial = ntrials;
-                new_cost = J_last;
-              }
             }
           }
           if (win_trial >= 0) {
             const int ws = store_slot(win_trial);
             if (ws < 0) {
-              replay_kind = (LEGACY && win_trial != 1) ? 1 : 0;
+              replay_kind = 0;
               replay_alpha = alpha_of(win_trial);
-              replay_ul = gid * G + win_lane;
               cur_slot = SS - 1;
               stage = ST_REPLAY;
             } else {
@@ -1579,7 +1725,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
           if (r0 >= 5) {
             n_trials += 5;
             if (!(bestJ >= old_cost)) {          // new_al_ilqr.h:1062
-              replay_kind = 0; replay_alpha = bestA; replay_ul = lg;
+              replay_kind = 0; replay_alpha = bestA;
               cur_slot = SS - 1;
               win_trial = 0;
               stage = ST_REPLAY;
@@ -1593,8 +1739,9 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
         }
         if (TRIP) break;                         // further passes in the following trips
       }
+      }
       PROF_MARK(4)
-     if (stage == ST_DONE) {
+     if (p >= 0 && stage == ST_DONE) {
       if (win_trial >= 0) cur_par = np_;
       __threadfence_block();
 
@@ -1640,10 +1787,26 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
         } else {
           // multiplier update vs penalty increase: ilqr.py:169-174 ; new_al_ilqr.h:1198-1211
           if (NEWAL ? !(viol > a.prm.viol_lambda) : (viol >= a.prm.viol_stop && viol < a.prm.viol_lambda)) {
-            for (int t = gl; t <= H; t += G) {
-              double x[N], u[M];
-              load_node(t, x, u);
-              OPS::update_lambda(a, tabC(t), x, u, rec(t) + (size_t)RL::rl * ES, ES, mu);
+            lmask0 = 0ull; lmask1 = 0ull;
+            for (int t0 = 0; t0 <= H; t0 += G) {
+              const int t = t0 + gl;
+              bool nz = false;
+              if (t <= H) {
+                double x[N], u[M];
+                load_node(t, x, u);
+                double* lp = rec(t) + (size_t)RL::rl * ES;
+                OPS::update_lambda(a, tabC(t), x, u, lp, ES, mu);
+                if (LEGACY) {
+#pragma unroll
+                  for (int i = 0; i < CL; ++i) nz |= (lp[(size_t)i * ES] != 0.0);
+                }
+              }
+              if (LEGACY) {
+                // the group's lanes hold nodes t0 .. t0+G-1: their flags, taken from the wave's ballot
+                const unsigned long long bits = (__ballot(nz) >> (lane & ~(G - 1))) & ((G >= 64) ? ~0ull : ((1ull << G) - 1ull));
+                if (t0 < 64) lmask0 |= bits << t0;
+                else if (t0 < 128) lmask1 |= bits << (t0 - 64);
+              }
             }
             __threadfence_block();
           } else {
@@ -1681,7 +1844,6 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
       phase = PH_LIN;
      }
       PROF_MARK(5)
-    }
   }
   PROF_FLUSH(a)
   // Every group leaves the loop after exactly one failing pull, so the counter ends at base + B + NG.
