@@ -1,23 +1,26 @@
 #!/usr/bin/env python3
 """Throughput of the batched AL-iLQR solve path on MI355X.
 
-One "step" = one complete solve of the workload batch: 4096 lateral-bicycle
-problems (H=50, box-constrained, start states randomised with seed = rank), the
-configuration BASELINE.json quotes the solves/sec metric on.  Inputs are
-resident in HBM before the timed region; every rank owns its own batches (weak
-scaling, no collective inside the solve; one gather of the final cost vectors
-over RCCL at the end of the K steps is the only exchange).
+One "step" = one complete solve of the workload batch.  The default workload is the configuration BASELINE.json
+quotes the solves/sec metric on: 4096 lateral-bicycle problems (H=50, box-constrained, start states randomised
+with seed = rank) per GPU, weak scaling.  Inputs are resident in HBM before the timed region; problems never
+exchange data, so the ranks shard the batch with no collective inside the solve; one gather of the final cost
+vectors over RCCL at the end of the K steps is the only exchange.
 
 Consecutive steps are independent batches.  They are enqueued on --pipeline (default 6) HIP streams in turn, each
 with its own output buffers and its own scratch inside the library, so the next batches fill the SIMDs that the
-tail of a batch leaves idle (a batch ends when its longest solve ends; the mean wave is busy ~40 % of a lone
-launch).  The process asks the HIP runtime for 16 hardware queues (--hw-queues): with the default 4, streams share
-queues and their kernels run one after the other.  All K steps complete inside the timed region; --pipeline 1
-gives the one-launch-at-a-time number.
+tail of a batch leaves idle (a batch ends when its longest solve ends).  The process asks the HIP runtime for 16
+hardware queues (--hw-queues): with the default 4, streams share queues and their kernels run one after the other.
+All K steps complete inside the timed region; --pipeline 1 gives the one-launch-at-a-time number.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config 2|3|4a|4b|5] [--scaling weak|strong] [--batch B]
+
+--config selects the other BASELINE configurations (3: kinematic model + rectangle obstacles, C++ generation;
+4a / 4b: dynamic model, H = 100, Python generations; 5: multi-start, 256 starts per scenario).  --scaling strong
+shards a fixed global batch (--batch) over the ranks (whole scenarios for config 5); weak gives every rank --batch.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,19 +31,45 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from ilqr_amd import batch, capi, problems  # noqa: E402
+from ilqr_amd import batch, capi, problems, sharding  # noqa: E402
 
-# Algorithmic fp64 operation counts per node (lateral model), dense as the
-# reference computes them; a transcendental call is counted as ONE operation.
-LAT_FLOPS = dict(bwd=469, lin=60 + 4, quad=40, dyn=30 + 6, cost=60)
+# Algorithmic fp64 operation counts per node, dense as the reference computes them (4-state / 6-state models);
+# a transcendental call is counted as ONE operation.
+FLOPS = {4: dict(bwd=469, lin=60 + 4, quad=40, dyn=30 + 6, cost=60),
+         6: dict(bwd=1752, lin=180 + 4, quad=64, dyn=50 + 6, cost=96)}
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector fp64 (half the 157.3 TF fp32 vector rate)
 HBM_PEAK_GBS = 8000.0
+STARTS = 256                     # config 5: starts per scenario
+
+CONFIGS = {
+    "2": dict(batch=4096, scaling="weak", label="lat-bicycle AL-iLQR (ILQR + LatBicycleKinematicNode, box constraints), H=50"),
+    "3": dict(batch=65536, scaling="strong", label="kinematic bicycle + linear table + rectangle obstacles (NewALILQR), H=50"),
+    "4a": dict(batch=16384, scaling="strong", label="dynamic bicycle (ILQR + FullBicycleDynamicNode, box), H=100"),
+    "4b": dict(batch=16384, scaling="strong", label="dynamic bicycle (FastILQR + FastBicycleNode, box + linear rows), H=100"),
+    "5": dict(batch=STARTS * 1024, scaling="strong", label="multi-start lat-bicycle (NewALILQR line search), 256 starts x scenarios, H=50"),
+}
 
 
-def algorithmic_flops(status, H):
+def make_workload(config, B, seed):
+    """(problem tuple, optional-input kwargs) for B problems of a configuration."""
+    if config == "2":
+        return problems.lat_legacy(B, 50, seed=seed), {}
+    if config == "3":
+        return problems.kin_rect(B, seed=1 + seed)
+    if config == "4a":
+        return problems.full_legacy("dyn", B, 100, 2 + seed), {}
+    if config == "4b":
+        return problems.fast_box_linear(B, seed=2 + seed), {}
+    if config == "5":
+        *prob, uo = problems.multi_start(B // STARTS, STARTS, seed=3 + seed)
+        return tuple(prob), dict(u_offset=uo)
+    raise SystemExit(f"unknown --config {config}")
+
+
+def algorithmic_flops(status, H, n):
     n_inner = status[:, 0].astype(np.float64).sum()
     n_trials = status[:, 3].astype(np.float64).sum()
-    f = LAT_FLOPS
+    f = FLOPS[n]
     return n_inner * H * (f["lin"] + f["quad"] + f["bwd"]) + n_trials * (H * f["dyn"] + (H + 1) * f["cost"])
 
 
@@ -49,8 +78,31 @@ def algorithmic_bytes(desc):
     return 8.0 * B * (n + (H + 1) * n + H * m + 1) + 16.0 * B
 
 
-def cpu_baseline(sample, seconds_hint=20.0):
-    """The CPU oracle (a restatement of the reference, 'port') on a bounded sample of the same workload."""
+def kernel_source_id():
+    """Hash of the kernel sources: counters measured on another build are not reported as this build's."""
+    h = hashlib.sha1()
+    for f in ("solver.hpp", "models.hpp", "trig.hpp", "launch.hpp", "alilqr_api.hip"):
+        with open(os.path.join(ROOT, "ilqr_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def measured_counters(config):
+    """HBM traffic per launch and VALU counters from the committed rocprofv3 --pmc passes of THIS build, or None."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    try:
+        with open(path) as fh:
+            c = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    if c.get("kernel_source_id") != kernel_source_id() or str(c.get("config")) != config:
+        return None
+    c["source"] = "profiles/r02_pmc.json"
+    return c
+
+
+def cpu_baseline(sample):
+    """The CPU oracle (a restatement of the reference, 'port') on a bounded sample of the default workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     threads = max(1, min(16, os.cpu_count() or 1, oracle_lib.lib().oracle_max_threads()))
@@ -67,7 +119,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
+    ap.add_argument("--batch", type=int, default=0, help="problems per GPU (weak) or in total (strong); 0 = the configuration's")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = the library's choice)")
@@ -76,11 +130,13 @@ def main():
                     help="GPU_MAX_HW_QUEUES for this process (HIP's default of 4 makes streams share a hardware "
                          "queue, and kernels on one queue run one after the other); 0 leaves the environment's value")
     ap.add_argument("--force-dist", action="store_true",
-                    help="rehearsal: take the multi-rank path (process group, per-step gather, barriers) with one rank too")
+                    help="rehearsal: take the multi-rank path (process group, gather, barriers) with one rank too")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) is the product path; gloo only rehearses the multi-rank control flow on a box "
                          "with fewer GPUs than ranks (ranks then share devices and the gather goes through the host)")
     args = ap.parse_args()
+    if args.steps < 1:
+        raise SystemExit("--steps must be >= 1")
 
     if args.hw_queues > 0:
         os.environ["GPU_MAX_HW_QUEUES"] = str(min(32, args.hw_queues))     # read by the HIP runtime when it starts
@@ -108,21 +164,45 @@ def main():
 
     if args.lanes:
         capi.set_tuning(lanes=args.lanes)
-    B, H = args.batch, 50
-    desc, x0, goals, Q, R, cons = problems.lat_legacy(B, H, seed=rank)
+    cfg = CONFIGS[args.config]
+    scaling = args.scaling or cfg["scaling"]
+    total = args.batch or cfg["batch"]
+    unit = STARTS if args.config == "5" else 1          # config 5 shards whole scenarios
+    if scaling == "strong":
+        lo, hi = sharding.shard_range(total // unit, rank, world)
+        B, global_B = (hi - lo) * unit, (total // unit) * unit
+        prob, kw = make_workload(args.config, global_B, 0)     # every rank generates the global batch, takes its shard
+        desc, x0, goals, uo = sharding.local_problem(prob[0], prob[1], prob[2], kw.get("u_offset"), lo * unit, hi * unit)
+        prob = (desc, x0, goals) + tuple(prob[3:])
+        if uo is not None:
+            kw["u_offset"] = uo
+    else:
+        B = (total // unit) * unit
+        global_B = B * world
+        prob, kw = make_workload(args.config, B, rank)
+    desc = prob[0]
+    H, n = desc.horizon, desc.n
+    if B < 1:
+        raise SystemExit("this rank has no problems: use a larger --batch")
+
     depth = max(1, min(8, args.pipeline))
-    solvers = [batch.BatchSolver(desc, x0, goals, Q, R, cons, extras=False, device=dev) for _ in range(depth)]
+    solvers = [batch.BatchSolver(*prob, extras=False, device=dev, **kw) for _ in range(depth)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
     # The only exchange of the job: one gather (RCCL) of the cost vectors the solve streams hold when the K steps
     # are done, inside the timed region.  The solves themselves need no collective.
-    final = torch.empty((depth, B), dtype=torch.float64, device=gdev) if multi else None
-    gathered = torch.empty((world, depth, B), dtype=torch.float64, device=gdev) if multi else None
+    maxB = B
+    if multi:
+        t = torch.tensor([B], dtype=torch.int64, device=gdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        maxB = int(t.item())
+    final = torch.zeros((depth, maxB), dtype=torch.float64, device=gdev) if multi else None
+    gathered = torch.empty((world, depth, maxB), dtype=torch.float64, device=gdev) if multi else None
 
     def gather_costs():
         for i, sv in enumerate(solvers):
             torch.cuda.current_stream(dev).wait_stream(streams[i])
-            final[i].copy_(sv.out["cost"])
+            final[i, :B].copy_(sv.out["cost"])
         dist.all_gather_into_tensor(gathered.view(-1), final.view(-1))
 
     # set-up, not a step: every stream's first solve allocates that stream's scratch inside the library
@@ -151,6 +231,7 @@ def main():
     torch.cuda.synchronize(dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
+    out = None
     for k in range(args.steps):
         out = step(k, ev[k])
     if multi:
@@ -175,61 +256,54 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     status = out["status"].cpu().numpy()
     cost = out["cost"].cpu().numpy()
-    flops = algorithmic_flops(status, H)
+    flops = algorithmic_flops(status, H, n)
     tf = flops / (kernel_ms * 1e-3) / 1e12                       # per launch, as each launch experienced it
     tf_job = flops * args.steps / dt / 1e12                      # all launches of the timed region over its wall time
     hit_cap = float(np.mean((status[:, 2] & capi.FLAG_OUTER_CAP) != 0))
+    viol_ok = float(np.mean((status[:, 2] & capi.FLAG_VIOL_OK) != 0))
 
     if rank == 0:
-        # counters of the same launch, collected in separate rocprofv3 --pmc passes (tools/profile_round.sh)
-        traffic = valu_active = executed = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                with open(pmc) as fh:
-                    counters = json.load(fh)
-                traffic = counters.get("hbm_bytes_per_launch")
-                if counters.get("SQ_WAVE_CYCLES"):
-                    valu_active = counters["SQ_ACTIVE_INST_VALU"] / counters["SQ_WAVE_CYCLES"]
-                executed = counters.get("executed_fp64_lane_flops_per_launch")
-            except (OSError, ValueError, KeyError):
-                traffic = valu_active = executed = None
+        value = global_B * args.steps / dt
+        pmc = measured_counters(args.config)
         line = {
-            "metric": "converged AL-iLQR solves/sec (H=50, batch N)",
-            "value": world * B * args.steps / dt,
+            "metric": f"converged AL-iLQR solves/sec (H={H}, batch N)",
+            "value": value,
             "unit": "solves/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "lat-bicycle AL-iLQR (ILQR + LatBicycleKinematicNode, box constraints), H=50, "
-                                   f"batch {B} per GPU, start states x0=(0,U(-1,1),U(-0.2,0.2),U(-0.05,0.05)) seed=rank",
-                       "batch_per_gpu": B, "horizon": H, "mode": "legacy", "model": "lat",
+            "config": {"workload": f"BASELINE config {args.config}: {cfg['label']}, "
+                                   + (f"batch {B} per GPU, start states seeded by rank" if scaling == "weak"
+                                      else f"global batch {global_B} sharded over {world} GPU(s)"),
+                       "config": args.config, "batch_per_gpu": B, "global_batch": global_B, "horizon": H,
                        "lanes_per_problem": args.lanes or "auto",
                        "batches_in_flight": depth, "lone_launch_ms": lone_ms,
                        # latency of one iLQR iteration (linearise, backward sweep, line search) of one problem with the
                        # whole batch resident: a lone launch lasts as long as its longest solve
                        "per_iter_latency_us": lone_ms * 1e3 / max(1, int(status[:, 0].max())),
                        "mean_inner_iters": float(status[:, 0].mean()), "mean_rollouts": float(status[:, 3].mean()),
-                       "frac_outer_cap": hit_cap, "frac_nonfinite": float(np.mean(~np.isfinite(cost)))},
+                       # "converged" = reached the reference generation's own stopping state: violation below its
+                       # tolerance, or its outer-iteration cap (the reference stops there too); both shares are given
+                       "frac_viol_below_tol": viol_ok, "frac_outer_cap": hit_cap,
+                       "solves_per_s_viol_below_tol": value * viol_ok,
+                       "frac_nonfinite": float(np.mean(~np.isfinite(cost)))},
             "roofline": {"bound": "valu_fp64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
-                         "valu_active_share_of_wave_cycles": valu_active,
-                         # fp64 flops the hardware executed (FMA, ADD, MUL instruction counters x 64 lanes, masked lanes
-                         # included) over the job's wall time: the machine-side utilisation beside the algorithmic one
-                         "executed_fp64_TFLOPs_job": (executed * args.steps / dt / 1e12) if executed else None,
-                         "executed_fp64_frac_job": (executed * args.steps / dt / 1e12 / FP64_VALU_PEAK_TFLOPS) if executed else None,
+                         "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                         # HBM bytes per launch from the PMC passes of this build (null when none is committed for it)
+                         "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+                         "counters": pmc,
                          "kernel": "alilqr::solve_kernel", "kernel_ms": kernel_ms,
                          "achieved_job": tf_job, "frac_job": tf_job / FP64_VALU_PEAK_TFLOPS,
                          "algorithmic_flops_per_launch": flops,
                          "algorithmic_hbm_bytes_per_launch": algorithmic_bytes(desc),
                          "hbm_GBs_algorithmic": algorithmic_bytes(desc) / (kernel_ms * 1e-3) / 1e9,
-                         "hbm_peak_GBs": HBM_PEAK_GBS},
+                         "hbm_peak_GBs": HBM_PEAK_GBS, "kernel_source_id": kernel_source_id()},
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)

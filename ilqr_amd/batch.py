@@ -36,7 +36,7 @@ def _require_gpu(device):
 
 
 def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=True, u_offset=None,
-                left_obs=None, right_obs=None, first_row=0):
+                left_obs=None, right_obs=None, first_row=0, trace=0):
     """Solve ``desc.batch`` problems on the GPU.
 
     Inputs may be numpy arrays or torch tensors (moved to ``device`` as fp64):
@@ -44,6 +44,8 @@ def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=
     ``u_offset`` [B,H,m] (optional) perturbs the controls of the initial guess: B starts of one scenario.
     ``left_obs`` / ``right_obs`` (optional, NEW_AL): lists of 2x4 rectangle vertex matrices whose y-bounds are
     written into the nodes' constraint tables while the solve runs; ``first_row`` is the row index the nodes start from.
+    ``trace`` > 0 also returns iter_cost / trials [B,trace]: the cost after every inner iteration and the roll-outs
+    of its line search (what the reference prints while it runs); entries beyond status[:,0] are NaN / 0.
     Returns a dict of device tensors: x [B,H+1,n], u [B,H,m], cost [B], status [B,4] and, with
     ``extras``, node_x, node_u, x_init, u_init, viol, lam, mu.
     """
@@ -73,6 +75,10 @@ def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=
     f64 = dict(dtype=torch.float64, device=dev)
     out = dict(x=torch.empty((B, H + 1, n), **f64), u=torch.empty((B, H, m), **f64), cost=torch.empty((B,), **f64),
                status=torch.zeros((B, capi.STATUS_WORDS), dtype=torch.int32, device=dev))
+    if trace > 0:
+        out.update(iter_cost=torch.full((B, int(trace)), float("nan"), **f64),
+                   trials=torch.zeros((B, int(trace)), dtype=torch.int32, device=dev))
+        ex.trace_cost, ex.trace_trials, ex.trace_cap = out["iter_cost"].data_ptr(), out["trials"].data_ptr(), int(trace)
     if extras:
         out.update(node_x=torch.empty((B, H + 1, n), **f64), node_u=torch.empty((B, H, m), **f64),
                    x_init=torch.empty((B, H + 1, n), **f64), u_init=torch.empty((B, H, m), **f64),
@@ -93,13 +99,21 @@ def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=
 class BatchSolver:
     """Inputs resident in HBM, outputs pre-allocated: ``run()`` only enqueues the solve."""
 
-    def __init__(self, desc, x0, goals, Q, R, cons, extras=False, device="cuda:0"):
+    def __init__(self, desc, x0, goals, Q, R, cons, extras=False, device="cuda:0", u_offset=None,
+                 left_obs=None, right_obs=None, first_row=0):
         torch = _torch()
         self.lib = capi.load_library()
         self.dev = _require_gpu(device)
         self.desc = desc
         B, H, n, m, c = desc.batch, desc.horizon, desc.n, desc.m, desc.c
         self.inputs = [_dev_f64(a, self.dev) for a in (x0, goals, Q, R, cons)]
+        # optional inputs of alilqr_solve_batch_ex: multi-start control offsets, rectangle obstacles
+        self.ex = None
+        lo, ro = capi.pack_rectangles(left_obs), capi.pack_rectangles(right_obs)
+        if u_offset is not None or len(lo) or len(ro):
+            self._keep = [None if u_offset is None else _dev_f64(u_offset, self.dev),
+                          _dev_f64(lo, self.dev) if len(lo) else None, _dev_f64(ro, self.dev) if len(ro) else None]
+            self.ex = capi.Extras(*[None if t is None else t.data_ptr() for t in self._keep], len(lo), len(ro), int(first_row), 0)
         f64 = dict(dtype=torch.float64, device=self.dev)
         self.out = dict(x=torch.empty((B, H + 1, n), **f64), u=torch.empty((B, H, m), **f64),
                         cost=torch.empty((B,), **f64),
@@ -113,15 +127,20 @@ class BatchSolver:
         never allocates (solves that overlap on one GPU must then not use it at the same time)."""
         torch = _torch()
         o = self.out
+        if noalloc and self.ex is not None:
+            raise ValueError("the allocation-free entry point takes no optional inputs")
         fn = self.lib.alilqr_solve_batch_noalloc if noalloc else self.lib.alilqr_solve_batch
+        outs = (_ptr(o["x"]), _ptr(o["u"]), _ptr(o.get("node_x")), _ptr(o.get("node_u")),
+                None, None, _ptr(o["cost"]), _ptr(o.get("viol")), None, _ptr(o.get("mu")), _ptr(o["status"]))
         # the library launches on the device that is current on the calling thread
         with torch.cuda.device(self.dev):
             if stream_ptr is None:
                 stream_ptr = torch.cuda.current_stream(self.dev).cuda_stream
-            rc = fn(C.byref(self.desc), *[_ptr(t) for t in self.inputs],
-                    _ptr(o["x"]), _ptr(o["u"]), _ptr(o.get("node_x")), _ptr(o.get("node_u")),
-                    None, None, _ptr(o["cost"]), _ptr(o.get("viol")), None, _ptr(o.get("mu")),
-                    _ptr(o["status"]), C.c_void_p(stream_ptr))
+            if self.ex is not None:
+                rc = self.lib.alilqr_solve_batch_ex(C.byref(self.desc), *[_ptr(t) for t in self.inputs], C.byref(self.ex),
+                                                    *outs, C.c_void_p(stream_ptr))
+            else:
+                rc = fn(C.byref(self.desc), *[_ptr(t) for t in self.inputs], *outs, C.c_void_p(stream_ptr))
         capi.check(rc, "alilqr_solve_batch_noalloc" if noalloc else "alilqr_solve_batch")
         return o
 
@@ -173,5 +192,27 @@ def node_aux_batch(desc, x, u, lam, mu, goals, Q, R, cons, device="cuda:0"):
                                        _ptr(out["cval"]), _ptr(out["lam_new"]), _ptr(out["viol"]),
                                        _ptr(out.get("par_cost")), _ptr(out.get("fxx")), C.c_void_p(stream))
         capi.check(rc, "alilqr_node_aux_batch")
+        torch.cuda.synchronize(dev)
+    return out
+
+
+def constraints_batch(desc, x, u, cons, device="cuda:0"):
+    """constraints(x,u), one column of parallel_constraints, and constraints_jacobian of a constraint table on
+    B*(H+1) points in parallel (FAST / NEW_AL tables)."""
+    torch = _torch()
+    lib = capi.load_library()
+    dev = _require_gpu(device)
+    B, H, n, m, c = desc.batch, desc.horizon, desc.n, desc.m, desc.c
+    zeros = (np.zeros((B, H + 1, c)), np.ones(B), np.zeros((H + 1, n)), np.eye(n), np.eye(m))
+    ins = [_dev_f64(a, dev) for a in (x, u) + zeros + (cons,)]
+    f64 = dict(dtype=torch.float64, device=dev)
+    out = dict(cval=torch.empty((B, H + 1, c), **f64), par_cval=torch.empty((B, H + 1, c), **f64),
+               jac_x=torch.empty((B, H + 1, c, n), **f64), jac_u=torch.empty((B, H + 1, c, m), **f64))
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.alilqr_constraints_batch(C.byref(desc), *[_ptr(t) for t in ins],
+                                          _ptr(out["cval"]), _ptr(out["par_cval"]), _ptr(out["jac_x"]), _ptr(out["jac_u"]),
+                                          C.c_void_p(stream))
+        capi.check(rc, "alilqr_constraints_batch")
         torch.cuda.synchronize(dev)
     return out

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 STATUS_WORDS = 4
 
 MODELS = {"lat": 0, "kin": 1, "dyn": 2, "dyn_mid": 3, "lat_k": 4, "new_bicycle": 5, "lon": 6, "lat_interior": 7}
@@ -44,7 +44,8 @@ class Problem(C.Structure):
 class Extras(C.Structure):
     """struct alilqr_extras (pointers are device pointers for the HIP library, host pointers for the test oracle)"""
     _fields_ = [("u_offset", C.c_void_p), ("left_obs", C.c_void_p), ("right_obs", C.c_void_p),
-                ("n_left", C.c_int32), ("n_right", C.c_int32), ("first_row", C.c_int32), ("reserved", C.c_int32)]
+                ("n_left", C.c_int32), ("n_right", C.c_int32), ("first_row", C.c_int32), ("reserved", C.c_int32),
+                ("trace_cost", C.c_void_p), ("trace_trials", C.c_void_p), ("trace_cap", C.c_int32), ("reserved2", C.c_int32)]
 
 
 def pack_rectangles(rects):
@@ -130,7 +131,7 @@ LIB_PATH = os.environ.get("ALILQR_LIB") or os.path.join(os.path.dirname(os.path.
 
 EXPORTS = ("alilqr_abi_version", "alilqr_last_error", "alilqr_device_count", "alilqr_default_params",
            "alilqr_workspace_bytes", "alilqr_solve_batch", "alilqr_solve_batch_multistart", "alilqr_solve_batch_ex",
-           "alilqr_linearize_batch", "alilqr_node_aux_batch",
+           "alilqr_linearize_batch", "alilqr_node_aux_batch", "alilqr_constraints_batch",
            "alilqr_release", "alilqr_solve_batch_noalloc", "alilqr_static_scratch_bytes", "alilqr_set_tuning")
 
 
@@ -170,6 +171,8 @@ def load_library():
     lib.alilqr_node_aux_batch.restype = C.c_int32
     lib.alilqr_node_aux_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 14
     lib.alilqr_linearize_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17
+    lib.alilqr_constraints_batch.restype = C.c_int32
+    lib.alilqr_constraints_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 13
     lib.alilqr_release.restype = C.c_int32
     lib.alilqr_solve_batch_noalloc.restype = C.c_int32
     lib.alilqr_solve_batch_noalloc.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17

@@ -241,6 +241,7 @@ struct LArgs {
   const double *x, *u, *lam, *mu, *goals, *Q, *R, *cons;
   double *f, *fx, *fu, *l, *lx, *lu, *lxx, *luu;
   double *cval, *lam_new, *viol, *pcost, *fxx;   // alilqr_node_aux_batch
+  double *pcval, *cjx, *cju;                     // alilqr_constraints_batch
 };
 
 template <int MODEL, int MODE>
@@ -313,6 +314,31 @@ __global__ __launch_bounds__(256) void linearize_kernel(LArgs a) {
     }
   }
   if (a.viol) a.viol[i] = OPS::violation(ka, tab, x, u, lam, 1, mu);
+  // ---- constraint object calls (alilqr_constraints_batch): table generations only
+  if constexpr (MODE != ALILQR_MODE_LEGACY) {
+    const int Cn = a.C;
+    if (a.pcval)
+      for (int q = 0; q < Cn; ++q) {
+        if constexpr (is_new_al(MODE)) a.pcval[i * Cn + q] = OPS::par_cval(ka, tab, x, u, q, lam, 1);
+        else a.pcval[i * Cn + q] = OPS::cval(ka, tab, x, u, q);
+      }
+    if (a.cjx)
+      for (int q = 0; q < Cn; ++q)
+        for (int j = 0; j < N; ++j) {
+          double v = tab[q * N + j];
+          if (a.quad) {
+            // row q of c_x: A_q + 2 Qc_q x   (quadratic_constraints.h:47-55)
+            ctab Qi = tab + Cn * (N + M + 1) + (size_t)q * N * N;
+            double qx = 0.0;
+            for (int k = 0; k < N; ++k) qx += (2 * Qi[j * N + k]) * x[k];
+            v = v + qx;
+          }
+          a.cjx[(i * Cn + q) * N + j] = v;
+        }
+    if (a.cju)
+      for (int q = 0; q < Cn; ++q)
+        for (int j = 0; j < M; ++j) a.cju[(i * Cn + q) * M + j] = tab[Cn * N + q * M + j];
+  }
   if constexpr (is_new_al(MODE)) {
     if (a.pcost) a.pcost[i] = OPS::par_cost(ka, Q, R, tab, x, u, g, lam, 1, mu);
     if (a.fxx) {
@@ -517,6 +543,9 @@ static int32_t solve_impl(const alilqr_problem* p,
 #ifdef ALILQR_PROF
   HIP_TRY(hipMemsetAsync(base + pl.counter + 128, 0, 128, st));   /* phase counters of profiling builds */
 #endif
+#ifdef ALILQR_DEBUG_BOUNDS
+  HIP_TRY(hipMemsetAsync(base + pl.counter + 32, 0, 4, st));      /* violation bits of debug builds */
+#endif
 
   alilqr::KArgs ka{};
   ka.B = p->batch; ka.NG = pl.NG; ka.H = p->horizon; ka.C = p->c;
@@ -526,6 +555,10 @@ static int32_t solve_impl(const alilqr_problem* p,
   ka.eq = (p->cons_kind & ALILQR_CONS_EQUALITY) ? 1 : 0;
   ka.prm = p->prm;
   ka.x0 = x0; ka.goals = goals; ka.Q = Q; ka.R = R; ka.cons = cons; ka.u_off = u_offset;
+  if (ex && (ex->trace_cost || ex->trace_trials)) {
+    if (ex->trace_cap < 1) { set_err("trace_cap must be positive"); return ALILQR_E_ARG; }
+    ka.trace_cost = ex->trace_cost; ka.trace_trials = ex->trace_trials; ka.trace_cap = ex->trace_cap;
+  }
   if (rect) { ka.left_obs = ex->left_obs; ka.right_obs = ex->right_obs; ka.n_left = n_left; ka.n_right = n_right; ka.first_row = ex->first_row; }
   ka.x_out = x_out; ka.u_out = u_out; ka.node_x = node_x; ka.node_u = node_u;
   ka.x_init = x_init; ka.u_init = u_init; ka.cost = cost; ka.viol = viol; ka.lam = lam; ka.mu = mu;
@@ -604,7 +637,7 @@ static int32_t node_eval(const alilqr_problem* p,
                          double* f, double* fx, double* fu, double* l,
                          double* lx, double* lu, double* lxx, double* luu,
                          double* cval, double* lam_new, double* viol, double* pcost, double* fxx,
-                         void* stream) {
+                         void* stream, double* pcval = nullptr, double* cjx = nullptr, double* cju = nullptr) {
   Dims d;
   int32_t rc = check_problem(p, &d);
   if (rc != ALILQR_OK) return rc;
@@ -622,6 +655,8 @@ static int32_t node_eval(const alilqr_problem* p,
   a.mc = {p->L, p->dt, p->v, p->k};
   a.x = x; a.u = u; a.lam = lam; a.mu = mu; a.goals = goals; a.Q = Q; a.R = R; a.cons = cons;
   a.cval = cval; a.lam_new = lam_new; a.viol = viol; a.pcost = pcost; a.fxx = fxx;
+  a.pcval = pcval; a.cjx = cjx; a.cju = cju;
+  if ((pcval || cjx || cju) && p->mode == ALILQR_MODE_LEGACY) { set_err("constraint tables exist for FAST and NEW_AL"); return ALILQR_E_ARG; }
   a.f = f; a.fx = fx; a.fu = fu; a.l = l; a.lx = lx; a.lu = lu; a.lxx = lxx; a.luu = luu;
   const size_t total = (size_t)p->batch * (p->horizon + 1);
   dim3 block(256), grid((unsigned)((total + 255) / 256));
@@ -670,6 +705,27 @@ int32_t alilqr_node_aux_batch(const alilqr_problem* p,
   return node_eval(p, x, u, lam, mu, goals, Q, R, cons, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                    cval, lam_new, viol, par_cost, fxx, stream);
 }
+
+int32_t alilqr_constraints_batch(const alilqr_problem* p,
+                                 const double* x, const double* u,
+                                 const double* lam, const double* mu,
+                                 const double* goals, const double* Q, const double* R, const double* cons,
+                                 double* cval, double* par_cval, double* jac_x, double* jac_u,
+                                 void* stream) {
+  return node_eval(p, x, u, lam, mu, goals, Q, R, cons, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                   cval, nullptr, nullptr, nullptr, nullptr, stream, par_cval, jac_x, jac_u);
+}
+
+#ifdef ALILQR_DEBUG_BOUNDS
+/* debug builds only: the violation bits of the last solve on this device (0 = every offset was in range) */
+int32_t alilqr_debug_read(unsigned* out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || !g_last_ws[dev]) return ALILQR_E_HIP;
+  if (hipDeviceSynchronize() != hipSuccess) return ALILQR_E_HIP;
+  if (hipMemcpy(out, (char*)g_last_ws[dev] + 32, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return ALILQR_E_HIP;
+  return ALILQR_OK;
+}
+#endif
 
 #ifdef ALILQR_PROF
 /* profiling builds only: copy the 9 phase counters of the last solve on this device to the host */

@@ -42,6 +42,15 @@
 
 namespace alilqr {
 
+// Debug builds (-DALILQR_DEBUG_BOUNDS): every computed workspace offset is checked before it is used.  A violation
+// sets bit `code` of a word in the scratch's counter block (read back by alilqr_debug_read) and the offset is
+// clamped, so a bad index is reported instead of faulting the GPU.
+#ifdef ALILQR_DEBUG_BOUNDS
+#define ALILQR_CHK(cond, code) ((cond) ? true : (atomicOr(a.counter + 8, 1u << (code)), false))
+#else
+#define ALILQR_CHK(cond, code) (true)
+#endif
+
 #ifdef ALILQR_PROF
 #define PROF_DECL unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PROF_MARK(i) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += t_ - prof_t0; prof_t0 = t_; }
@@ -80,6 +89,9 @@ struct KArgs {
   const double *left_obs, *right_obs;   // rectangle obstacles [n][2][4] (NEW_AL row activation), or null
   int n_left, n_right, first_row;
   const double* u_off;        // optional [B][H][m] added to the controls of the initial guess (multi-start), or null
+  double* trace_cost;         // optional [B][trace_cap]: cost after every inner iteration, or null
+  int32_t* trace_trials;      // optional [B][trace_cap]: roll-outs of every inner iteration's line search, or null
+  int trace_cap;
   double *x_out, *u_out, *node_x, *node_u, *x_init, *u_init, *cost, *viol, *lam, *mu;
   int32_t* status;
   double *trj, *blk, *ucum;
@@ -948,6 +960,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
   double new_cost = 0.0, J_last = 0.0, replay_alpha = 0.0, bestJ = 0.0, bestA = 0.0;
   bool keep_old = false, gate_skip = false, have = false;
   int win_trial = -1, win_lane = -1, r0 = 0, replay_kind = 0;
+  int nt0 = 0;                // roll-out count when the running line search started (trace output)
   // LEGACY: bit t set = some multiplier of node t is not zero (nodes 0 .. 127; longer horizons load them always).
   // A roll-out step reads the node's multipliers only then: they are all zero during the first outer iteration
   // and on most nodes later.
@@ -958,11 +971,20 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
   // run and a node's (x, u) is one short run; G = 1: [parity][element][group * SS + slot], lane-minor, so the
   // 64 problems of a wave store one contiguous run per element.
   auto trj_at = [&](int par, int off, int slot) -> double* {
+    if (!ALILQR_CHK(par >= 0 && par < 2, 0)) par = 0;
+    if (!ALILQR_CHK(off >= 0 && off < T, 1)) off = 0;
+    if (!ALILQR_CHK(slot >= 0 && slot < SS, 2)) slot = 0;
     if (PM) return trj + ((gid * 2 + par) * SS + slot) * (size_t)T + off;
     return trj + ((size_t)par * T + off) * (NG * SS) + gid * SS + slot;
   };
-  auto rec = [&](int t) -> double* { return blk + (size_t)t * RS * ES; };
-  auto lrec = [&](int t) -> double* { return linb + (size_t)t * NR::E * ES; };
+  auto rec = [&](int t) -> double* {
+    if (!ALILQR_CHK(t >= 0 && t <= H, 3)) t = 0;
+    return blk + (size_t)t * RS * ES;
+  };
+  auto lrec = [&](int t) -> double* {
+    if (!ALILQR_CHK(t >= 0 && t <= H, 4)) t = 0;
+    return linb + (size_t)t * NR::E * ES;
+  };
 #ifdef ALILQR_LIT_LAT   /* timing experiment only: the tables of the headline problem as literals */
   auto tabQ = [&](int) { return (ctab)kLitQ; };
   auto tabR = [&](int) { return (ctab)kLitR; };
@@ -1021,7 +1043,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
       int np = 0;
       if (gl == 0) np = (int)(atomicAdd(a.counter, 1u) - a.counter_base);
       np = gbcast_i<G>(np, 0);
-      if (np >= a.B) {
+      if (np >= a.B || !ALILQR_CHK(np >= 0, 11)) {
         drained = true;
       } else {
         p = np;
@@ -1361,6 +1383,7 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
       }
       __threadfence_block();
       // ---- a new line search starts
+      nt0 = n_trials;
       new_cost = old_cost;
       keep_old = false;                          // NEW_AL: the trial costs were not finite, the trajectory stays
       win_trial = -1; win_lane = -1;
@@ -1426,8 +1449,18 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
         double J = 0.0;
         double x[N];
         const double mu = tg.mu;                       // shadows the group's own penalty
-        double* const tout = tg.trjp + (size_t)(sslot >= 0 ? sslot : 0) * T;
-        auto rec = [&](int t) -> double* { return tg.blk + (size_t)t * RS * ES; };
+        (void)ALILQR_CHK(sslot < SS, 5);
+        const size_t bdoubles = block_doubles<MD, MODE>(H, C);
+        (void)ALILQR_CHK(tg.blk >= a.blk && tg.blk + bdoubles <= a.blk + NG * bdoubles, 6);
+        (void)bdoubles;
+        (void)ALILQR_CHK(tg.trjp >= trj && tg.trjp + (size_t)SS * T <= trj + NG * 2 * SS * (size_t)T, 7);
+        (void)ALILQR_CHK(tg.cur >= trj && tg.cur + T <= trj + NG * 2 * SS * (size_t)T, 8);
+        (void)ALILQR_CHK(!(LEGACY && kind == 1 && valid) || (ucol >= a.ucum && ucol + (size_t)(US - 1) * ucs < a.ucum + NG * (size_t)US * ucs), 9);
+        double* const tout = tg.trjp + (size_t)(sslot >= 0 && sslot < SS ? sslot : 0) * T;
+        auto rec = [&](int t) -> double* {
+          if (!ALILQR_CHK(t >= 0 && t <= H, 10)) t = 0;
+          return tg.blk + (size_t)t * RS * ES;
+        };
         const bool closed = !(LEGACY && kind == 1);
         RecRegs RA, RB;
         load_rec(tg, 0, RA, closed);
@@ -1591,6 +1624,8 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
             trial = win_trial;
             v = act && store_slot(win_trial) < 0;
           }
+          (void)ALILQR_CHK(!v || (trial >= 1 && trial <= ntrials), 12);
+          (void)ALILQR_CHK(gid_t < NG, 13);
           kind = (trial != 1) ? 1 : 0;
           sslot = !v ? -1 : (pass == PASS_C) ? ((gl == 0) ? SS - 1 : -1) : store_slot(trial);
           const double J = rollout(tg, v, kind, 1.0, a.ucum + gid_t * UC + (size_t)(trial >= 2 ? trial - 2 : 0), UCS, sslot);
@@ -1747,6 +1782,10 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
 
       // ================= P4: inner / outer bookkeeping (ilqr.py:158-174) =================
       ++n_inner; ++inner;
+      if (gl == 0 && n_inner <= a.trace_cap) {
+        if (a.trace_cost) a.trace_cost[(size_t)p * a.trace_cap + (n_inner - 1)] = new_cost;
+        if (a.trace_trials) a.trace_trials[(size_t)p * a.trace_cap + (n_inner - 1)] = n_trials - nt0;
+      }
       // inner stop rule: |dJ| < tol (ilqr.py:162) ; 0 <= J_old - J_new < tol (new_al_ilqr.h:1118)
       const bool brk = NEWAL ? ((old_cost - new_cost < a.prm.inner_tol) && (old_cost - new_cost >= 0))
                              : (fabs(new_cost - old_cost) < a.prm.inner_tol);

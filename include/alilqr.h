@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ALILQR_ABI_VERSION 3
+#define ALILQR_ABI_VERSION 4
 
 /* ---- vehicle model (node type) ------------------------------------------
  * LAT      4 states / 1 control   cilqr/lat_bicycle_node.py:4-91
@@ -222,6 +222,14 @@ typedef struct alilqr_extras {
   int32_t first_row;         /* initial row index of every node's table: set_current_constraints_index()
                                 (constraints.h:189-196), 0 if never called */
   int32_t reserved;          /* 0 */
+  /* Optional per-iteration trace (both NULL: none): what the reference prints per inner iteration
+   * (cilqr/ilqr.py:157-167, fast_ilqr.py:142-152; new_al_ilqr.h:1100-1121): entry i of problem b holds the cost after
+   * inner iteration i (counted over the whole solve) and the number of roll-outs its line search made.  Iterations
+   * beyond trace_cap are not recorded; entries beyond status[0] are left untouched. */
+  double* trace_cost;        /* [B][trace_cap] or NULL */
+  int32_t* trace_trials;     /* [B][trace_cap] or NULL */
+  int32_t trace_cap;         /* entries per problem */
+  int32_t reserved2;         /* 0 */
 } alilqr_extras;
 
 /* alilqr_solve_batch with the optional inputs above (ex may be NULL). */
@@ -278,6 +286,23 @@ int32_t alilqr_node_aux_batch(const alilqr_problem* p,
                               const double* goals, const double* Q, const double* R, const double* cons,
                               double* cval, double* lam_new, double* viol, double* par_cost, double* fxx,
                               void* stream);
+
+/*
+ * The calls of the reference's constraint objects (the Linear / Box / Quadratic classes of ilqr_pybind,
+ * al_ilqr_cpp/constraints/constraints_bind.h:47-50, 88-91; FAST / NEW_AL tables) on B*(H+1) independent points
+ * (inputs as in alilqr_linearize_batch; every output may be NULL):
+ *   cval     [B][H+1][c]      constraints(x, u)            linear_constraints.h:176-181, quadratic_constraints.h:15-27
+ *   par_cval [B][H+1][c]      one column of parallel_constraints(X, U): the quadratic term is added last
+ *                             (linear_constraints.h:218-224, quadratic_constraints.h:29-45)
+ *   jac_x    [B][H+1][c][n]   constraints_jacobian(x, u).first  = A (+ 2 Qc_i x per row for quadratic tables)
+ *   jac_u    [B][H+1][c][m]   constraints_jacobian(x, u).second = B    (linear_constraints.h:260-265, quadratic_constraints.h:47-55)
+ */
+int32_t alilqr_constraints_batch(const alilqr_problem* p,
+                                 const double* x, const double* u,
+                                 const double* lam, const double* mu,
+                                 const double* goals, const double* Q, const double* R, const double* cons,
+                                 double* cval, double* par_cval, double* jac_x, double* jac_u,
+                                 void* stream);
 
 /* Release every cached device workspace of the calling process (waits for the solves in flight). */
 int32_t alilqr_release(void);

@@ -539,6 +539,11 @@ static double compute_total_cost(py_solver* s) {           /* ilqr.py:52-56 */
 
 _Thread_local const double* or_u_offset = NULL;
 _Thread_local const alilqr_extras* or_extras = NULL;
+_Thread_local double or_min_margin = 1.0;
+static double* or_margin_out = NULL;      /* [B], set by oracle_set_margin_out: where batch solves record their margins */
+
+/* Ask the following oracle_solve_batch* calls to record every solve's decision margin in out[B] (NULL: stop). */
+void oracle_set_margin_out(double* out) { or_margin_out = out; }
 
 /* ilqr.py:11-50 / fast_ilqr.py:10-49 */
 static void linearized_initial_guess(py_solver* s, double* x, double* u) {
@@ -701,6 +706,7 @@ static void forward(py_solver* s, const double* kff, const double* Kfb,
     }
     double new_cost = compute_total_cost(s);
     ++trials;
+    or_decision(new_cost, old_cost);
     if (new_cost < old_cost) break;
     alpha = alpha / 2.0;
     if (legacy) { nu = u; nx = x; }          /* ilqr.py:137-138: new_u = u ; new_x = x */
@@ -776,12 +782,19 @@ static int py_optimize(const alilqr_problem* p, or_node* nodes,
       forward(&s, kff, Kfb, buf[g][0], buf[g][1], buf[g][2], buf[g][3], &nx, &nu);
       double new_cost = compute_total_cost(&s);
       if (trace && trace->length < trace->capacity) trace->iter_cost[trace->length++] = new_cost;
+      {
+        /* |dJ| against the tolerance, on the scale of J (that is where the rounding of dJ lives) */
+        double sc = fmax(fabs(new_cost), fabs(old_cost));
+        or_decision(sc + (fabs(new_cost - old_cost) - p->prm.inner_tol), sc);
+      }
       if (fabs(new_cost - old_cost) < p->prm.inner_tol) break;
       x = nx; u = nu; gen = g;
       old_cost = new_cost;
     }
     violation = compute_violation(&s);
     ++n_outer;
+    or_decision(violation, p->prm.viol_stop);
+    or_decision(violation, p->prm.viol_lambda);
     if (violation < p->prm.viol_stop) { flags |= ALILQR_FLAG_VIOL_OK; break; }
     else if (violation >= p->prm.viol_stop && violation < p->prm.viol_lambda) {
       for (int t = 0; t <= H; ++t) {
@@ -864,6 +877,7 @@ int32_t oracle_solve_batch_ex(const alilqr_problem* p,
     const double* g = goals + ((p->goal_batch > 1) ? (size_t)b * xs : 0);
     or_u_offset = (ex && ex->u_offset) ? ex->u_offset + (size_t)b * us : NULL;
     or_extras = ex;
+    or_min_margin = 1.0;
     int r = oracle_solve(p, x0 + (size_t)b * n, g, Q, R, cons,
                          x_out ? x_out + b * xs : NULL, u_out ? u_out + b * us : NULL,
                          node_x ? node_x + b * xs : NULL, node_u ? node_u + b * us : NULL,
@@ -873,6 +887,7 @@ int32_t oracle_solve_batch_ex(const alilqr_problem* p,
                          status ? status + (size_t)b * ALILQR_STATUS_WORDS : NULL, NULL);
     or_u_offset = NULL;
     or_extras = NULL;
+    if (or_margin_out) or_margin_out[b] = or_min_margin;
     if (r != 0) rc = r;
   }
   (void)threads;

@@ -80,6 +80,10 @@ int32_t oracle_node_aux_batch(const alilqr_problem* p,
 
 int32_t oracle_max_threads(void);
 
+/* Ask the following oracle_solve_batch* calls to record, per solve, its decision margin in out[B] (NULL: stop):
+ * the smallest relative distance between the two sides of any accept / reject / stop comparison the solve made. */
+void oracle_set_margin_out(double* out);
+
 #ifdef __cplusplus
 }
 #endif

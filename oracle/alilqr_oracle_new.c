@@ -570,8 +570,10 @@ static void nw_parallel_search(nw_solver* s, double alpha, double* best_alpha, d
     s->n_trials++;
   }
   int best = 0;
-  for (int c = 1; c < PARALLEL_NUM; ++c)
+  for (int c = 1; c < PARALLEL_NUM; ++c) {
+    or_decision(cost[c], cost[best]);
     if (cost[c] < cost[best]) best = c;
+  }
   *best_cost = cost[best];
   *best_alpha = av[best];
 }
@@ -611,6 +613,7 @@ static void nw_update_constraints(nw_solver* s) {
           double ex_ = vx[e2] - vx[e], ey_ = vy[e2] - vy[e];        /* edge vector */
           double qx = px - vx[e], qy = py - vy[e];
           double cr = qx * ey_ - qy * ex_;                            /* MultiVectorCross :215-222 */
+          or_decision(qx * ey_, qy * ex_);
           if (!(cr < 0)) inside = 0;
           if (side == 0) { if (vy[e] > ext) ext = vy[e]; } else { if (vy[e] < ext) ext = vy[e]; }
         }
@@ -632,10 +635,12 @@ static void nw_forward(nw_solver* s) {
   memcpy(s->pre_u, s->u, sizeof(double) * us);
   memcpy(s->pre_cost, s->cost_list, sizeof(double) * (H + 1));
   double alpha = 1.0, best_alpha = 1.0, best_cost = 0.0;
+  or_decision(fabs(s->dV_lin), s->p->prm.dv_gate);
   if (fabs(s->dV_lin) < s->p->prm.dv_gate) return;          /* the reference compares with the float literal 0.2F */
   for (int index = 0; index < 10; ++index) {
     nw_update_trajectory(s, alpha);
     new_cost = sum_cost(s);
+    or_decision(new_cost, old_cost);
     if (new_cost < old_cost) break;
     alpha /= 2.0;
     memcpy(s->x, s->pre_x, sizeof(double) * xs);
@@ -643,6 +648,7 @@ static void nw_forward(nw_solver* s) {
   }
   if (new_cost >= old_cost) {
     nw_parallel_search(s, alpha, &best_alpha, &best_cost);
+    or_decision(best_cost, old_cost);
     if (best_cost >= old_cost) {
       memcpy(s->x, s->pre_x, sizeof(double) * xs);
       memcpy(s->u, s->pre_u, sizeof(double) * us);
@@ -700,6 +706,11 @@ int32_t or_new_solve(const alilqr_problem* p,
         trace->iter_cost[trace->length] = new_cost;
         trace->trials[trace->length++] = (int32_t)(s.n_trials - before);
       }
+      {
+        double sc = fmax(fabs(new_cost), fabs(old_cost));
+        or_decision(sc + ((old_cost - new_cost) - p->prm.inner_tol), sc);
+        or_decision(old_cost, new_cost);
+      }
       if ((old_cost - new_cost < p->prm.inner_tol) && ((old_cost - new_cost) >= 0)) break;
     }
     double zero_u[OR_NU] = {0};
@@ -709,6 +720,8 @@ int32_t or_new_solve(const alilqr_problem* p,
       if (t == 0 || v > violation) violation = v;
     }
     ++n_outer;
+    or_decision(violation, p->prm.viol_stop);
+    or_decision(violation, p->prm.viol_lambda);
     if (violation < p->prm.viol_stop) { flags |= ALILQR_FLAG_VIOL_OK; break; }
     if (violation > p->prm.viol_lambda) {
       s.mu = s.mu * p->prm.mu_gain;

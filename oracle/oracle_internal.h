@@ -2,6 +2,7 @@
 #ifndef ORACLE_INTERNAL_H
 #define ORACLE_INTERNAL_H
 
+#include <math.h>
 #include "alilqr_oracle.h"
 
 #define OR_NX 6
@@ -38,6 +39,18 @@ extern _Thread_local const double* or_u_offset;
 
 /* optional inputs (rectangle obstacles, first row index) of the solve running on this thread, or NULL */
 extern _Thread_local const alilqr_extras* or_extras;
+
+/* Decision margin of the solve running on this thread: the smallest relative distance, over every accept / reject /
+ * stop comparison the solver made, between the two sides of the comparison.  A solve whose margin is far above the
+ * arithmetic noise (~1e-15) makes the same decisions in any implementation whose arithmetic differs in the last
+ * bits only; a solve with a margin at noise level is decided by rounding and cannot be pinned by anything. */
+extern _Thread_local double or_min_margin;
+static inline void or_decision(double lhs, double rhs) {
+  double sc = fabs(lhs) > fabs(rhs) ? fabs(lhs) : fabs(rhs);
+  if (!(sc > 0.0) || !isfinite(sc)) return;          /* both zero, or not finite: nothing rounding could flip */
+  double mg = fabs(lhs - rhs) / sc;
+  if (mg < or_min_margin) or_min_margin = mg;
+}
 
 /* NEW_AL generation (alilqr_oracle_new.c) */
 int32_t or_new_solve(const alilqr_problem* p,

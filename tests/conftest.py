@@ -25,6 +25,14 @@ def tuning():
     capi.set_tuning()
 
 
+def pytest_terminal_summary(terminalreporter):
+    import golden_util as gu
+    if gu.PINNED_LOG:
+        terminalreporter.write_line("solves covered by the 1e-6 parity assertions (pinned / total):")
+        for label, n, tot in gu.PINNED_LOG:
+            terminalreporter.write_line(f"  {label:60s} {n:5d} / {tot:<5d} {n / max(1, tot):.3f}")
+
+
 def _gpu_present():
     try:
         import torch

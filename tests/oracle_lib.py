@@ -37,7 +37,9 @@ def _p(a):
 
 def solve_batch(desc, x0, goals, Q, R, cons, threads=0, extras=True, u_offset=None, left_obs=None, right_obs=None,
                 first_row=0):
-    """Run the oracle on a batch; arrays are host numpy float64, C-contiguous."""
+    """Run the oracle on a batch; arrays are host numpy float64, C-contiguous.  With ``extras`` the result also holds
+    ``margin`` [B]: the smallest relative distance between the two sides of any accept / reject / stop comparison
+    the solve made (a solve with a margin at rounding level is decided by rounding)."""
     B, H, n, m, c = desc.batch, desc.horizon, desc.n, desc.m, desc.c
     out = capi.alloc_outputs_numpy(B, H, n, m, c, extras)
     args = [np.ascontiguousarray(a, dtype=np.float64) for a in (x0, goals, Q, R, cons)]
@@ -46,12 +48,17 @@ def solve_batch(desc, x0, goals, Q, R, cons, threads=0, extras=True, u_offset=No
     lo, ro = capi.pack_rectangles(left_obs), capi.pack_rectangles(right_obs)
     ex = capi.Extras(None if uo is None else uo.ctypes.data, lo.ctypes.data if len(lo) else None,
                      ro.ctypes.data if len(ro) else None, len(lo), len(ro), int(first_row), 0)
+    margin = np.ones(B) if extras else None
+    lib().oracle_set_margin_out(_p(margin))
     rc = lib().oracle_solve_batch_ex(C.byref(desc), *[_p(a) for a in args], C.byref(ex),
                                      _p(out["x"]), _p(out["u"]), _p(out.get("node_x")), _p(out.get("node_u")),
                                      _p(out.get("x_init")), _p(out.get("u_init")), _p(out["cost"]), _p(out.get("viol")),
                                      _p(out.get("lam")), _p(out.get("mu")), _p(out.get("status")), C.c_int32(threads))
+    lib().oracle_set_margin_out(None)
     if rc != 0:
         raise RuntimeError(f"oracle_solve_batch failed: {rc}")
+    if extras:
+        out["margin"] = margin
     return out
 
 
@@ -72,6 +79,22 @@ def solve_traced(desc, x0, goals, Q, R, cons, capacity=4096):
     out["iter_cost"] = ic[:trace.length].copy()
     out["trials"] = tr[:trace.length].copy()
     return out
+
+
+def solve_batch_traced(desc, x0, goals, Q, R, cons, capacity=1024):
+    """Per-iteration trace of every problem of a batch (one oracle_solve per problem): lists of iter_cost / trials."""
+    B, H, n = desc.batch, desc.horizon, desc.n
+    x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(B, n)
+    goals = np.ascontiguousarray(goals, dtype=np.float64)
+    d = type(desc).from_buffer_copy(desc)
+    d.batch = 1
+    d.goal_batch = 1
+    costs, trials = [], []
+    for i in range(B):
+        g = goals.reshape(B, H + 1, n)[i] if desc.goal_batch > 1 else goals
+        o = solve_traced(d, x0[i:i + 1], g, Q, R, cons, capacity)
+        costs.append(o["iter_cost"]); trials.append(o["trials"])
+    return costs, trials
 
 
 def linearize_batch(desc, x, u, lam, mu, goals, Q, R, cons):

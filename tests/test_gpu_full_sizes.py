@@ -35,12 +35,7 @@ def subset(prob, idx, u_offset=None):
 
 
 def worst_err(o, ref, i, j=None):
-    j = i if j is None else j
-    ex = gu.rel_err(o["x"][i], ref["x"][j])
-    eu = gu.rel_err(o["u"][i], ref["u"][j])
-    ec = abs(o["cost"][i] - ref["cost"][j]) / max(1.0, abs(ref["cost"][j]))
-    w = max(ex, eu, ec)
-    return w if np.isfinite(w) else np.inf
+    return gu.solve_err(o, ref, i, j)
 
 
 def check_full_batch(prob, kw, floor, u_offset=None, seed=0):
@@ -65,7 +60,7 @@ def check_full_batch(prob, kw, floor, u_offset=None, seed=0):
     bump = np.zeros_like(sub[1]); bump[:, 1] = 1e-13
     ref2 = ol.solve_batch(sub[0], sub[1] + bump, *sub[2:6], u_offset=uo, **kw)
     ok = np.array([worst_err(ref2, ref, i) < 1e-8 for i in range(SAMPLE)])
-    assert ok.mean() >= floor, ok.mean()
+    assert gu.pinned(f"full_sizes/sample of {full['cost'].shape[0]} ({sub[0].model}/{sub[0].mode})", ok) >= floor
     for i in np.nonzero(ok)[0]:
         assert worst_err(alone, ref, i) < TOL, (i, idx[i], alone["status"][i], ref["status"][i])
     return full

@@ -21,11 +21,7 @@ def to_np(out):
 
 
 def worst_err(o, ref, i):
-    ex = gu.rel_err(o["x"][i], ref["x"][i])
-    eu = gu.rel_err(o["u"][i], ref["u"][i])
-    ec = abs(o["cost"][i] - ref["cost"][i]) / max(1.0, abs(ref["cost"][i]))
-    w = max(ex, eu, ec)
-    return w if np.isfinite(w) else np.inf
+    return gu.solve_err(o, ref, i)
 
 
 def stable_mask(desc, x0, goals, Q, R, cons, ref, probes=2):
@@ -60,12 +56,14 @@ def test_new_al_matches_oracle(name, lanes, tuning):
     ref = ol.solve_batch(desc, x0, goals, Q, R, cons)
     o = to_np(batch.solve_batch(desc, x0, goals, Q, R, cons))
     ok = stable_mask(desc, x0, goals, Q, R, cons, ref)
-    assert ok.mean() >= FLOOR[name], (name, ok.mean())
+    assert gu.pinned(f"new_al/{name}/lanes={lanes}", ok) >= FLOOR[name], name
     for i in np.nonzero(ok)[0]:
         assert worst_err(o, ref, i) < TOL, (name, i, o["status"][i], ref["status"][i])
     assert gu.rel_err(o["x_init"], ref["x_init"]) < 1e-12
-    same = (o["status"][ok] == ref["status"][ok]).all(axis=1).mean()
-    assert same > 0.9, same
+    # same iteration / roll-out counts on the pinned solves, but for one in ten (at least one: a last-ulp difference of
+    # the device sin/cos can add or drop an iteration that changes nothing above 1e-6)
+    differ = int((o["status"][ok] != ref["status"][ok]).any(axis=1).sum())
+    assert differ <= max(1, int(0.1 * ok.sum())), (differ, int(ok.sum()))
     # properties every solve must have, stable or not
     fin = np.isfinite(o["cost"])
     assert np.array_equal(o["x"][:, 0], x0)
@@ -163,7 +161,7 @@ def test_new_al_equality_table_matches_oracle(model):
     ref = ol.solve_batch(desc, x0, goals, Q, R, cons)
     o = to_np(batch.solve_batch(desc, x0, goals, Q, R, cons))
     ok = stable_mask(desc, x0, goals, Q, R, cons, ref)
-    assert ok.mean() >= 0.5, ok.mean()
+    assert gu.pinned(f"new_al/equality/{model}", ok) >= 0.5
     for i in np.nonzero(ok)[0]:
         assert worst_err(o, ref, i) < TOL, (model, i, o["status"][i], ref["status"][i])
     # equality multipliers take both signs

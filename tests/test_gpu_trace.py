@@ -1,0 +1,75 @@
+"""Iteration-by-iteration parity: the per-iteration cost / line-search trace of the HIP solve against the oracle's.
+
+The whole-solve tests assert x, u and the final cost only on solves the oracle reproduces from a moved start state;
+the others (chaotic iterates, line searches decided by rounding) would be covered by nothing.  Here EVERY solve is
+compared, iteration by iteration, for as long as it is comparable: up to the first iteration at which the GPU, or one
+of three oracle runs from start states moved by ~1e-13, takes another number of line-search trials than the oracle.
+Inside that prefix the GPU's cost after every iteration must stay within the envelope of the oracle's own
+sensitivity: |J_gpu - J| <= max(1e-9 |J|, 1e3 x the largest |J_probe - J| of the three moved runs); the first
+iteration (same start, one linearisation, one backward sweep, one line search) to 1e-10 |J| or that envelope.
+Reference for what is traced: the cost / trial prints of cilqr/ilqr.py:157-167, fast_ilqr.py:142-152 and the
+iteration loop of al_ilqr_cpp/new_al_ilqr.h:1090-1122.
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle_lib as ol
+from ilqr_amd import batch, problems
+
+pytestmark = pytest.mark.gpu
+CAP = 512
+
+SETS = {
+    "lat_legacy": lambda: problems.lat_legacy(96, 50, seed=0),
+    "dyn_legacy_h100": lambda: problems.full_legacy("dyn", 16, 100, 2),
+    "kin_legacy": lambda: problems.full_legacy("kin", 24, 50, 1),
+    "fast_box": lambda: problems.fast_box(24),
+    "fast_box_linear_h100": lambda: problems.fast_box_linear(12),
+    "new_al_box6_active_bound": lambda: problems.new_al_box(32, y_max=20.0),
+    "new_al_circle4": lambda: problems.new_al_lat_circle(32),
+    "new_al_circle6": lambda: problems.new_al_circle(32),
+}
+
+
+def rel(a, b):
+    with np.errstate(invalid="ignore", over="ignore"):
+        e = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    both_bad = ~np.isfinite(a) & ~np.isfinite(b)
+    return np.where(both_bad, 0.0, np.where(np.isfinite(e), e, np.inf))
+
+
+@pytest.mark.parametrize("name", list(SETS))
+def test_iteration_trace_stays_inside_the_oracles_own_sensitivity(name):
+    prob = SETS[name]()
+    desc, x0 = prob[0], prob[1]
+    B = desc.batch
+    o = batch.solve_batch(*prob, trace=CAP)
+    gc, gt, st = o["iter_cost"].cpu().numpy(), o["trials"].cpu().numpy(), o["status"].cpu().numpy()
+    oc, ot = ol.solve_batch_traced(*prob, capacity=CAP)
+    rng = np.random.default_rng(7)
+    probes = [ol.solve_batch_traced(desc, x0 + rng.uniform(-1, 1, size=x0.shape) * 1e-13, *prob[2:6], capacity=CAP)
+              for _ in range(3)]
+    covered, total, whole = 0, 0, 0
+    for i in range(B):
+        n_or = len(oc[i])
+        L = min(n_or, min(CAP, int(st[i, 0])))
+        d = np.nonzero(gt[i, :L] != ot[i][:L])[0]
+        L = int(d[0]) if len(d) else L
+        env = np.zeros(L)
+        for pc, pt in probes:
+            Lp = min(L, len(pc[i]))
+            d = np.nonzero(pt[i][:Lp] != ot[i][:Lp])[0]
+            Lp = int(d[0]) if len(d) else Lp
+            L = min(L, Lp)
+            env = np.maximum(env[:L], rel(pc[i][:L], oc[i][:L]))
+        e = rel(gc[i, :L], oc[i][:L])
+        assert L >= 1, (name, i, "not even the first iteration is comparable")
+        assert e[0] < max(1e-10, 1e3 * env[0]), (name, i, e[0], env[0])
+        bad = np.nonzero(e > np.maximum(1e-9, 1e3 * env))[0]
+        assert len(bad) == 0, (name, i, int(bad[0]), e[bad[0]], env[bad[0]])
+        covered += L; total += n_or; whole += (L == n_or and int(st[i, 0]) == n_or)
+    gu.PINNED_LOG.append((f"trace/{name}: iterations compared", covered, total))
+    gu.PINNED_LOG.append((f"trace/{name}: solves compared to their last iteration", whole, B))
+    print(f"[trace] {name}: {covered}/{total} iterations compared ({covered / max(1, total):.3f}), {whole}/{B} solves to the end")
+    assert covered >= 0.05 * total

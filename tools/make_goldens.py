@@ -295,13 +295,19 @@ def run_set(name, p, x0s, jobs):
     with mp.Pool(jobs) as pool:
         both = pool.map(solve_one, [(p, x0) for x0 in x0s] + [(p, x0 + bump) for x0 in x0s], chunksize=1)
     res, res2 = both[:len(x0s)], both[len(x0s):]
-    # a solve is 'stable' when the reference itself reproduces it to 1e-8 from a start state moved by 1e-13
+    # a solve is 'stable' when the reference itself reproduces it to 1e-8 from a start state moved by 1e-13,
+    # measured per component like the parity tests do (tests/golden_util.py: |a-b| / max(|b|, floor of the component))
+    for extra in (os.path.dirname(os.path.dirname(OUT)), os.path.dirname(OUT)):
+        if extra not in sys.path:
+            sys.path.insert(0, extra)
+    import golden_util as gu
+
     def _same(a, b):
         if a is None or b is None:
             return False
         d = 0.0
         for key in ("x", "u", "node_x", "node_u"):
-            d = max(d, float(np.max(np.abs(a[key] - b[key])) / max(1.0, float(np.max(np.abs(a[key]))))))
+            d = max(d, gu.comp_err(b[key], a[key]))
         d = max(d, abs(a["cost"] - b["cost"]) / max(1.0, abs(a["cost"])))
         return bool(d < 1e-8)
     stable_all = np.array([_same(a, b) for a, b in zip(res, res2)])
