@@ -187,6 +187,20 @@ size_t block_doubles_for(const alilqr_problem* p, bool rect) {
   return block_doubles<Model<ALILQR_MODEL_DYN_MID>, ALILQR_MODE_FAST>(H, C);
 }
 
+// doubles of one linearisation record of a LEGACY solve
+int legacy_lin_doubles(const alilqr_problem* p, bool packed) {
+  using namespace alilqr;
+#define E_OF(m) (packed ? NodeRec<Model<m>, ALILQR_MODE_LEGACY, true>::E : NodeRec<Model<m>, ALILQR_MODE_LEGACY>::E)
+  switch (p->model) {
+    case ALILQR_MODEL_LAT: return E_OF(ALILQR_MODEL_LAT);
+    case ALILQR_MODEL_LON: return E_OF(ALILQR_MODEL_LON);
+    case ALILQR_MODEL_LAT_INTERIOR: return E_OF(ALILQR_MODEL_LAT_INTERIOR);
+    case ALILQR_MODEL_DYN: return E_OF(ALILQR_MODEL_DYN);
+    default: return E_OF(ALILQR_MODEL_KIN);
+  }
+#undef E_OF
+}
+
 // Layout of a solve's scratch.  `cap` > 0 bounds the total: the number of resident waves is reduced until the
 // scratch fits (the groups then pull more problems each); total == 0 says that not even one wave fits.
 Plan make_plan(const alilqr_problem* p, const Dims& d, bool rect = false, size_t cap = 0) {
@@ -194,6 +208,10 @@ Plan make_plan(const alilqr_problem* p, const Dims& d, bool rect = false, size_t
   pl.G = pick_group(p);
   long max_waves = 4096;
   { const long w = g_opt_max_waves.load(std::memory_order_relaxed); if (w > 0) max_waves = w; }
+  // a kernel built for one wave per SIMD (8-lane LEGACY groups with their records in LDS) has 1024 resident waves
+  if (p->mode == ALILQR_MODE_LEGACY && !g_opt_no_lds.load(std::memory_order_relaxed) &&
+      d.N <= 4 && alilqr::legacy_lds_mode(d.N, pl.G, p->horizon, legacy_lin_doubles(p, pl.G < 32)) == 1 && max_waves > 1024)
+    max_waves = 1024;
   long gpw = 64 / pl.G;                             // groups per wave
   long need_waves = ((long)p->batch + gpw - 1) / gpw;
   long waves = need_waves < max_waves ? need_waves : max_waves;

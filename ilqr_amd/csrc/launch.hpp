@@ -10,17 +10,35 @@ namespace alilqr {
 
 enum { LAUNCH_OK = 0, LAUNCH_BAD_WIDTH = 1, LAUNCH_FAILED = 2 };
 
+// Where the linearisation records of a LEGACY solve live (lds_mode): 0 in the groups' blocks in HBM; 2 in LDS with
+// two waves per SIMD (a wave's share of the 160 KB of a CU is 20 KB); 1 in LDS with one wave per SIMD (40 KB).
+// The sequential Riccati sweep then reads them with LDS latency and they cause no memory traffic.
+__host__ inline int legacy_lds_mode(int n_states, int G, int H, int rec_doubles) {
+  const size_t lds = (size_t)(64 / G) * (H + 1) * rec_doubles * sizeof(double);
+  const size_t share2 = 160 * 1024 / 8, share1 = 160 * 1024 / 4;
+  if (n_states <= 4) {
+    if ((G == 32 || G == 16) && lds <= share2) return 2;
+    if (G == 8 && lds <= share1) return 1;
+    return 0;
+  }
+  return ((G == 32 || G == 16) && lds <= share1) ? 1 : 0;
+}
+
 template <int MODEL, int MODE>
 inline int launch_family(const KArgs& ka, int G, int waves, hipStream_t st, int no_lds) {
   dim3 grid(waves), block(64);
   if constexpr (MODE == ALILQR_MODE_LEGACY) {
-    // 32-lane LEGACY kernels keep their linearisation records in LDS when two groups' worth of them fit eight
-    // (4-state, 2 waves per SIMD) or four (6-state, 1 wave per SIMD) times into the 160 KB of a CU
     using MDx = Model<MODEL>;
-    const size_t lds = (size_t)2 * (ka.H + 1) * NodeRec<MDx, MODE>::E * sizeof(double);
-    const size_t room = (MDx::N <= 4) ? 160 * 1024 / 8 : 160 * 1024 / 4;
-    if (G == 32 && lds <= room && !no_lds) {
-      hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32, true>), grid, block, lds, st, ka);
+    const int E = (G == 32) ? NodeRec<MDx, MODE>::E : NodeRec<MDx, MODE, true>::E;     // narrower groups pack their records
+    const int mode = no_lds ? 0 : legacy_lds_mode(MDx::N, G, ka.H, E);
+    const size_t lds = (size_t)(64 / G) * (ka.H + 1) * E * sizeof(double);
+    if (mode != 0) {
+      if (G == 32) hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32, true>), grid, block, lds, st, ka);
+      else if (G == 16) hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 16, true>), grid, block, lds, st, ka);
+      else {
+        if constexpr (MDx::N <= 4) hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 8, true, 1>), grid, block, lds, st, ka);
+        else return LAUNCH_BAD_WIDTH;
+      }
       return hipGetLastError() == hipSuccess ? LAUNCH_OK : LAUNCH_FAILED;
     }
   }

@@ -115,6 +115,32 @@ struct Model<ALILQR_MODEL_LAT> : Lat4Base {
     a[4] = dt * v * (tu * tu + 1) / L;
     b[0] = 0.5 * dt2 * v * (tu * tu + 1) / L;
   }
+  // The Jacobian entries above are products of constants with four values: sin / cos of the mid-point heading and
+  // tan^2 + 1 of the two steering angles.  A linearisation record keeps those four (NC) instead of the six entries;
+  // jac_unpack() repeats the products of jac() in the same order, so the entries come out with the same bits.
+  static constexpr int NC = 4;
+  template <bool WRAPPED = false>
+  __device__ static void jac_pack(const ModelConst& mc, const double* x, const double* uc, double* c) {
+    const double v = mc.v, dt = mc.dt, L = mc.L;
+    double th = wrap_in<WRAPPED>(x[2]), de = wrap_in<WRAPPED>(x[3]);
+    double td = tan_w(de);
+    double tm = th + 0.5 * dt * v * td / L;
+    double tu = tan_w(de + 0.5 * dt * uc[0]);
+    sincos_w(tm, &c[0], &c[1]);
+    c[2] = td * td + 1;
+    c[3] = tu * tu + 1;
+  }
+  __device__ static __forceinline__ void jac_unpack(const ModelConst& mc, const double* c, double* a, double* b) {
+    const double v = mc.v, dt = mc.dt, L = mc.L;
+    const double sm = c[0], cm = c[1];
+    double dt2 = dt * dt, v2 = v * v;
+    a[0] = -dt * v * sm;
+    a[1] = -0.5 * dt2 * v2 * c[2] * sm / L;
+    a[2] = dt * v * cm;
+    a[3] = 0.5 * dt2 * v2 * c[2] * cm / L;
+    a[4] = dt * v * c[3] / L;
+    b[0] = 0.5 * dt2 * v * c[3] / L;
+  }
 };
 
 // ---- lateral model with a squashed control (cilqr/lat_bicycle_interior_node.py) --------------------------------
@@ -517,6 +543,34 @@ struct Model<ALILQR_MODEL_NEW_BICYCLE> : Full6Base {
     return 0.0;
   }
   __host__ __device__ static constexpr bool fxx_nz(int i, int j) { return (i >= 2 && i <= 4) && (j >= 2 && j <= 4); }
+};
+
+// What a linearisation record keeps of a node's dynamics Jacobian: the model's packed form where it has one
+// (NC values, jac_pack / jac_unpack), else the compact entries themselves.
+template <class MD, class = void>
+struct JacPack {
+  static constexpr int NC = MD::NA + MD::NB;
+  template <bool WRAPPED>
+  __device__ static __forceinline__ void pack(const ModelConst& mc, const double* x, const double* u, double* c) {
+    MD::template jac<WRAPPED>(mc, x, u, c, c + MD::NA);
+  }
+  __device__ static __forceinline__ void unpack(const ModelConst&, const double* c, double* a, double* b) {
+#pragma unroll
+    for (int i = 0; i < MD::NA; ++i) a[i] = c[i];
+#pragma unroll
+    for (int i = 0; i < MD::NB; ++i) b[i] = c[MD::NA + i];
+  }
+};
+template <class MD>
+struct JacPack<MD, decltype((void)MD::NC)> {
+  static constexpr int NC = MD::NC;
+  template <bool WRAPPED>
+  __device__ static __forceinline__ void pack(const ModelConst& mc, const double* x, const double* u, double* c) {
+    MD::template jac_pack<WRAPPED>(mc, x, u, c);
+  }
+  __device__ static __forceinline__ void unpack(const ModelConst& mc, const double* c, double* a, double* b) {
+    MD::jac_unpack(mc, c, a, b);
+  }
 };
 
 }  // namespace alilqr

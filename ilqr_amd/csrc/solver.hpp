@@ -412,7 +412,7 @@ struct NodeOps<MODEL, ALILQR_MODE_LEGACY> {
   __device__ static void quadratize(const KArgs& a, ctab Q, ctab R, ctab box,
                                     const double* x, const double* u, const double* g,
                                     const double* lam, size_t ls, double mu,
-                                    double* rec, size_t rs) {
+                                    double* rec, size_t rs, int* code = nullptr) {
     using LL = LinLayout<MD>;
     double e[N], w[C], im[C];
 #pragma unroll
@@ -452,7 +452,24 @@ struct NodeOps<MODEL, ALILQR_MODE_LEGACY> {
         for (int j = 0; j < M; ++j) rec[(LL::oLuu + i * M + j) * rs] = (i == j) ? (2 * R[i * M + j] + 0.0) : 2 * R[i * M + j];
       }
     }
+    // The AL part of diag(l_xx), diag(l_uu) is 0, mu or mu + mu per entry (the two bounds of a variable):
+    // two bits each, states first.  hess_diag() turns them back into the same doubles.
+    if (code) {
+      int cd = 0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) cd |= ((im[i] != 0.0 ? 1 : 0) + (im[N + i] != 0.0 ? 1 : 0)) << (2 * i);
+      if constexpr (MD::CTRL_ROWS) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) cd |= ((im[2 * N + i] != 0.0 ? 1 : 0) + (im[2 * N + M + i] != 0.0 ? 1 : 0)) << (2 * (N + i));
+      }
+      *code = cd;
+    }
     (void)a;
+  }
+  // entry `idx` (states 0..N-1, then controls) of the AL part of the Hessian diagonal from the packed code
+  __device__ static __forceinline__ double hess_diag(int code, int idx, double mu) {
+    const int c = (code >> (2 * idx)) & 3;
+    return c == 0 ? 0.0 : (c == 1 ? mu : mu + mu);
   }
   // per-node term of the violation measure: || max(-lam/mu, c) ||_2  (cilqr/ilqr.py:186-192)
   __device__ static double violation(const KArgs& a, ctab box, const double* x, const double* u,
@@ -823,13 +840,18 @@ struct RecLayout {
   static constexpr int N = MD::N, M = MD::M;
   static constexpr int rK = 0, rk = rK + M * N, rl = rk + M;
 };
-template <class MD, int MODE>
+// PACK (LEGACY records that have to share a small LDS budget among many groups of a wave): the Jacobian in the
+// model's packed form (JacPack) and the AL part of the Hessian diagonal as one code word; the Riccati sweep expands
+// both with the arithmetic that produced the unpacked entries, so the bits are the same.
+template <class MD, int MODE, bool PACK = false>
 struct NodeRec {
   static constexpr int N = MD::N, M = MD::M;
   static constexpr bool LEGACY = (MODE == ALILQR_MODE_LEGACY);
   static constexpr bool NEWAL = is_new_al(MODE);
-  static constexpr int HX = LEGACY ? N : N * N, HU = LEGACY ? M : M * M, NF = NEWAL ? 7 : 0;
-  static constexpr int oA = 0, oB = oA + MD::NA, oLx = oB + MD::NB, oLu = oLx + N, oHx = oLu + M, oHu = oHx + HX,
+  static_assert(!PACK || LEGACY, "packed records exist for the LEGACY generation");
+  static constexpr int HX = PACK ? 1 : (LEGACY ? N : N * N), HU = PACK ? 0 : (LEGACY ? M : M * M), NF = NEWAL ? 7 : 0;
+  static constexpr int NJA = PACK ? JacPack<MD>::NC : MD::NA, NJB = PACK ? 0 : MD::NB;
+  static constexpr int oA = 0, oB = oA + NJA, oLx = oB + NJB, oLu = oLx + N, oHx = oLu + M, oHu = oHx + HX,
                        oF = oHu + HU, E = (oF + NF + 1) & ~1;
 };
 
@@ -872,15 +894,18 @@ struct FxxOf<MD, true> {
   }
 };
 
-template <int MODEL, int MODE, int G, bool LDSLIN = false>
-__global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) void solve_kernel(KArgs a) {
+// MINW: waves per SIMD the instantiation is compiled for (0: 2 for the 4-state models, 1 for the 6-state ones).
+// One wave per SIMD gives a wave 512 registers and a 40 KB share of the LDS.
+template <int MODEL, int MODE, int G, bool LDSLIN = false, int MINW = 0>
+__global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1))) void solve_kernel(KArgs a) {
   using MD = Model<MODEL>;
   using OPS = NodeOps<MODEL, MODE>;
   using LL = LinLayout<MD>;
   using RL = RecLayout<MD>;
-  using NR = NodeRec<MD, MODE>;
   constexpr int N = MD::N, M = MD::M;
   constexpr bool LEGACY = (MODE == ALILQR_MODE_LEGACY);
+  constexpr bool PACK = LEGACY && LDSLIN && (G < 32);  // many groups per wave share the wave's LDS: packed records
+  using NR = NodeRec<MD, MODE, PACK>;
   constexpr bool NEWAL = is_new_al(MODE);
   constexpr bool QUAD = is_quad(MODE);
   constexpr bool RECT = is_rect(MODE);
@@ -1259,12 +1284,19 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
 #pragma unroll
         for (int i = 0; i < N; ++i) g[i] = goal_of(p)[(size_t)t * N + i];
         if (t < H) {
-          double ac[MD::NA], bc[MD::NB];
-          MD::template jac<!NEWAL>(mc, x, u, ac, bc);
+          if constexpr (PACK) {
+            double jc[NR::NJA];
+            JacPack<MD>::template pack<true>(mc, x, u, jc);
 #pragma unroll
-          for (int i = 0; i < MD::NA; ++i) lr[(size_t)(NR::oA + i) * ES] = ac[i];
+            for (int i = 0; i < NR::NJA; ++i) lr[(size_t)(NR::oA + i) * ES] = jc[i];
+          } else {
+            double ac[MD::NA], bc[MD::NB];
+            MD::template jac<!NEWAL>(mc, x, u, ac, bc);
 #pragma unroll
-          for (int i = 0; i < MD::NB; ++i) lr[(size_t)(NR::oB + i) * ES] = bc[i];
+            for (int i = 0; i < MD::NA; ++i) lr[(size_t)(NR::oA + i) * ES] = ac[i];
+#pragma unroll
+            for (int i = 0; i < MD::NB; ++i) lr[(size_t)(NR::oB + i) * ES] = bc[i];
+          }
           if (NEWAL) {
             double ff[8];
             FxxOf<MD, NEWAL>::eval(mc, x, u, ff);
@@ -1273,19 +1305,23 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
           }
         }
         double q[LL::E];
-        if (LEGACY) {
+        if constexpr (LEGACY) {
           double lam[CL];
 #pragma unroll
           for (int i = 0; i < CL; ++i) lam[i] = r[(size_t)(RL::rl + i) * ES];
-          OPS::quadratize(a, tabQ(t), tabR(t), tabC(t), x, u, g, lam, 1, mu, q, 1);
-          // l_xx = 2Q + diag, l_uu = 2R + diag: keep the AL part of the diagonal only (2Q, 2R are uniform tables)
-          ctab Q = tabQ(t);
-          ctab R = tabR(t);
+          // l_xx = 2Q + diag, l_uu = 2R + diag: the record keeps the diagonal only (2Q, 2R are uniform tables), or,
+          // packed, the code of its AL part
+          if constexpr (PACK) {
+            int hcode = 0;
+            OPS::quadratize(a, tabQ(t), tabR(t), tabC(t), x, u, g, lam, 1, mu, q, 1, &hcode);
+            lr[(size_t)NR::oHx * ES] = (double)hcode;
+          } else {
+            OPS::quadratize(a, tabQ(t), tabR(t), tabC(t), x, u, g, lam, 1, mu, q, 1);
 #pragma unroll
-          for (int i = 0; i < N; ++i) lr[(size_t)(NR::oHx + i) * ES] = q[LL::oLxx + i * N + i];
+            for (int i = 0; i < N; ++i) lr[(size_t)(NR::oHx + i) * ES] = q[LL::oLxx + i * N + i];
 #pragma unroll
-          for (int i = 0; i < M; ++i) lr[(size_t)(NR::oHu + i) * ES] = q[LL::oLuu + i * M + i];
-          (void)Q; (void)R;
+            for (int i = 0; i < M; ++i) lr[(size_t)(NR::oHu + i) * ES] = q[LL::oLuu + i * M + i];
+          }
         } else {
           OPS::quadratize(a, tabQ(t), tabR(t), tabC(t), x, u, g, r + (size_t)RL::rl * ES, ES, mu, q, 1);
 #pragma unroll
@@ -1332,7 +1368,8 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
             Vx[i] = LH.v[NR::oLx + i];
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-              if constexpr (LEGACY) Vxx[i][j] = (i == j) ? LH.v[NR::oHx + i] : 2 * Q[i * N + j];
+              if constexpr (PACK) Vxx[i][j] = (i == j) ? 2 * Q[i * N + j] + OPS::hess_diag((int)LH.v[NR::oHx], i, mu) : 2 * Q[i * N + j];
+              else if constexpr (LEGACY) Vxx[i][j] = (i == j) ? LH.v[NR::oHx + i] : 2 * Q[i * N + j];
               else Vxx[i][j] = LHt.v[NR::oHx - EA + i * N + j];
             }
           }
@@ -1342,18 +1379,28 @@ __global__ __launch_bounds__(64, (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1)) vo
           if (!LEGACY) load_late(t, Lt);
           if (t > 0) load_lin(t - 1, Lnext);            // in flight while this step computes
           double S[N][N], Bm[N][M], K[M][N], kf[M], dl;
-          expand_jac<MD>(mc, &L.v[NR::oA], &L.v[NR::oB], S, Bm);
+          int hcode = 0;
+          if constexpr (PACK) {
+            double ac[MD::NA], bc[MD::NB];
+            JacPack<MD>::unpack(mc, &L.v[NR::oA], ac, bc);
+            expand_jac<MD>(mc, ac, bc, S, Bm);
+            hcode = (int)L.v[NR::oHx];
+          } else {
+            expand_jac<MD>(mc, &L.v[NR::oA], &L.v[NR::oB], S, Bm);
+          }
           ctab Q = tabQ(t);
           ctab R = tabR(t);
           riccati_step<MD>(S, Bm,
                            [&](int i) { return L.v[NR::oLx + i]; },
                            [&](int r) { return L.v[NR::oLu + r]; },
                            [&](int i, int j) {
-                             if constexpr (LEGACY) return (i == j) ? L.v[NR::oHx + i] : 2 * Q[i * N + j];
+                             if constexpr (PACK) return (i == j) ? 2 * Q[i * N + j] + OPS::hess_diag(hcode, i, mu) : 2 * Q[i * N + j];
+                             else if constexpr (LEGACY) return (i == j) ? L.v[NR::oHx + i] : 2 * Q[i * N + j];
                              else return Lt.v[NR::oHx - EA + i * N + j];
                            },
                            [&](int r, int b) {
-                             if constexpr (LEGACY) return (r == b) ? L.v[NR::oHu + r] : 2 * R[r * M + b];
+                             if constexpr (PACK) return (r == b) ? 2 * R[r * M + b] + OPS::hess_diag(hcode, N + r, mu) : 2 * R[r * M + b];
+                             else if constexpr (LEGACY) return (r == b) ? L.v[NR::oHu + r] : 2 * R[r * M + b];
                              else return Lt.v[NR::oHu - EA + r * M + b];
                            },
                            [&](double acc, int i, int j, const double* Vo) {
