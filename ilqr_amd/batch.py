@@ -36,7 +36,7 @@ def _require_gpu(device):
 
 
 def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=True, u_offset=None,
-                left_obs=None, right_obs=None, first_row=0, trace=0):
+                left_obs=None, right_obs=None, first_row=0, trace=0, mu_solver=None, first_rows=None, overlay=False):
     """Solve ``desc.batch`` problems on the GPU.
 
     Inputs may be numpy arrays or torch tensors (moved to ``device`` as fp64):
@@ -44,6 +44,10 @@ def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=
     ``u_offset`` [B,H,m] (optional) perturbs the controls of the initial guess: B starts of one scenario.
     ``left_obs`` / ``right_obs`` (optional, NEW_AL): lists of 2x4 rectangle vertex matrices whose y-bounds are
     written into the nodes' constraint tables while the solve runs; ``first_row`` is the row index the nodes start from.
+    NEW_AL state carried between optimize() calls of one solver object: ``mu_solver`` [B] is the solver-level penalty
+    the previous call left (the result then holds ``mu_solver`` [B]); ``first_rows`` [H+1] gives every node its own
+    start row; ``overlay`` returns ``overlay`` [B,H+1,2c+1]: the rows the rectangle activation wrote (signs, constants,
+    final row index per node).
     ``trace`` > 0 also returns iter_cost / trials [B,trace]: the cost after every inner iteration and the roll-outs
     of its line search (what the reference prints while it runs); entries beyond status[:,0] are NaN / 0.
     Returns a dict of device tensors: x [B,H+1,n], u [B,H,m], cost [B], status [B,4] and, with
@@ -75,6 +79,23 @@ def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=
     f64 = dict(dtype=torch.float64, device=dev)
     out = dict(x=torch.empty((B, H + 1, n), **f64), u=torch.empty((B, H, m), **f64), cost=torch.empty((B,), **f64),
                status=torch.zeros((B, capi.STATUS_WORDS), dtype=torch.int32, device=dev))
+    keep = []
+    if desc.mode == capi.MODES["new_al"]:
+        out["mu_solver"] = torch.empty((B,), **f64)
+        ex.mu_solver_out = out["mu_solver"].data_ptr()
+        if mu_solver is not None:
+            ms = _dev_f64(np.broadcast_to(np.asarray(mu_solver, dtype=np.float64), (B,)), dev)
+            keep.append(ms)
+            ex.mu_solver_in = ms.data_ptr()
+    if first_rows is not None:
+        fr = torch.as_tensor(np.ascontiguousarray(first_rows, dtype=np.int32), device=dev)
+        if fr.numel() != H + 1:
+            raise ValueError("first_rows must hold H+1 values")
+        keep.append(fr)
+        ex.first_rows = fr.data_ptr()
+    if overlay:
+        out["overlay"] = torch.zeros((B, H + 1, 2 * c + 1), **f64)
+        ex.overlay_out = out["overlay"].data_ptr()
     if trace > 0:
         out.update(iter_cost=torch.full((B, int(trace)), float("nan"), **f64),
                    trials=torch.zeros((B, int(trace)), dtype=torch.int32, device=dev))

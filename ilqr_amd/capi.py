@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 STATUS_WORDS = 4
 
 MODELS = {"lat": 0, "kin": 1, "dyn": 2, "dyn_mid": 3, "lat_k": 4, "new_bicycle": 5, "lon": 6, "lat_interior": 7}
@@ -45,7 +45,9 @@ class Extras(C.Structure):
     """struct alilqr_extras (pointers are device pointers for the HIP library, host pointers for the test oracle)"""
     _fields_ = [("u_offset", C.c_void_p), ("left_obs", C.c_void_p), ("right_obs", C.c_void_p),
                 ("n_left", C.c_int32), ("n_right", C.c_int32), ("first_row", C.c_int32), ("reserved", C.c_int32),
-                ("trace_cost", C.c_void_p), ("trace_trials", C.c_void_p), ("trace_cap", C.c_int32), ("reserved2", C.c_int32)]
+                ("trace_cost", C.c_void_p), ("trace_trials", C.c_void_p), ("trace_cap", C.c_int32), ("reserved2", C.c_int32),
+                ("mu_solver_in", C.c_void_p), ("mu_solver_out", C.c_void_p), ("first_rows", C.c_void_p),
+                ("overlay_out", C.c_void_p)]
 
 
 def pack_rectangles(rects):

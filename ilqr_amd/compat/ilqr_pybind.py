@@ -6,4 +6,6 @@ from ilqr_amd.pybind_api import (BoxConstraints4_1, BoxConstraints6_2, LinearCon
                                  NewBicycleNodeBoxConstraints6_2, NewBicycleNodeLinearConstraints6_2_16,
                                  NewLatBicycleNodeBoxConstraints4_1, NewLatBicycleNodeLinearConstraints4_1_6,
                                  NewLatBicycleNodeLinearConstraints4_1_10, QuadraticConstraints4_1_3, QuadraticConstraints6_2_5,
-                                 NewBicycleNodeQuadraticConstraints6_2_5, NewLatBicycleNodeQuadraticConstraints4_1_3)
+                                 NewBicycleNodeQuadraticConstraints6_2_5, NewLatBicycleNodeQuadraticConstraints4_1_3,
+                                 Constraints6_2_16, Constraints6_2_5, Constraints4_1_10, Constraints4_1_6, Constraints4_1_3,
+                                 ILQRNode6_2, ILQRNode4_1)

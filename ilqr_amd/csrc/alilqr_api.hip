@@ -577,6 +577,11 @@ static int32_t solve_impl(const alilqr_problem* p,
     if (ex->trace_cap < 1) { set_err("trace_cap must be positive"); return ALILQR_E_ARG; }
     ka.trace_cost = ex->trace_cost; ka.trace_trials = ex->trace_trials; ka.trace_cap = ex->trace_cap;
   }
+  if (ex && (ex->mu_solver_in || ex->mu_solver_out || ex->first_rows || ex->overlay_out)) {
+    if (p->mode != ALILQR_MODE_NEW_AL) { set_err("mu_solver / first_rows / overlay_out are defined for NEW_AL"); return ALILQR_E_ARG; }
+    if ((ex->first_rows || ex->overlay_out) && !rect) { set_err("first_rows / overlay_out need rectangle obstacles"); return ALILQR_E_ARG; }
+    ka.mu_s_in = ex->mu_solver_in; ka.mu_s_out = ex->mu_solver_out; ka.first_rows = ex->first_rows; ka.overlay_out = ex->overlay_out;
+  }
   if (rect) { ka.left_obs = ex->left_obs; ka.right_obs = ex->right_obs; ka.n_left = n_left; ka.n_right = n_right; ka.first_row = ex->first_row; }
   ka.x_out = x_out; ka.u_out = u_out; ka.node_x = node_x; ka.node_u = node_u;
   ka.x_init = x_init; ka.u_init = u_init; ka.cost = cost; ka.viol = viol; ka.lam = lam; ka.mu = mu;

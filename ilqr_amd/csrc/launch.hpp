@@ -42,6 +42,11 @@ inline int launch_family(const KArgs& ka, int G, int waves, hipStream_t st, int 
       return hipGetLastError() == hipSuccess ? LAUNCH_OK : LAUNCH_FAILED;
     }
   }
+#ifdef ALILQR_ONLY_G   /* development builds: one lane-group width only (seconds to compile) */
+  if (G != ALILQR_ONLY_G) return LAUNCH_BAD_WIDTH;
+  hipLaunchKernelGGL((solve_kernel<MODEL, MODE, ALILQR_ONLY_G>), grid, block, 0, st, ka);
+  return hipGetLastError() == hipSuccess ? LAUNCH_OK : LAUNCH_FAILED;
+#else
   switch (G) {
     case 1: hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 1>), grid, block, 0, st, ka); break;
     case 4: hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 4>), grid, block, 0, st, ka); break;
@@ -51,6 +56,7 @@ inline int launch_family(const KArgs& ka, int G, int waves, hipStream_t st, int 
     default: return LAUNCH_BAD_WIDTH;
   }
   return hipGetLastError() == hipSuccess ? LAUNCH_OK : LAUNCH_FAILED;
+#endif
 }
 
 #define ALILQR_FAMILY_NAME_(m, k) launch_m##m##_k##k

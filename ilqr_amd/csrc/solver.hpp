@@ -92,6 +92,10 @@ struct KArgs {
   double* trace_cost;         // optional [B][trace_cap]: cost after every inner iteration, or null
   int32_t* trace_trials;      // optional [B][trace_cap]: roll-outs of every inner iteration's line search, or null
   int trace_cap;
+  const double* mu_s_in;      // NEW_AL, optional [B]: the solver-level penalty a previous optimize() left (null: 1)
+  double* mu_s_out;           // NEW_AL, optional [B]: the solver-level penalty after this solve
+  const int32_t* first_rows;  // RECT, optional [H+1]: per-node initial row index (null: first_row)
+  double* overlay_out;        // RECT, optional [B][H+1][2C+1]: row signs | replacement constants | row index per node
   double *x_out, *u_out, *node_x, *node_u, *x_init, *u_init, *cost, *viol, *lam, *mu;
   int32_t* status;
   double *trj, *blk, *ucum;
@@ -514,6 +518,19 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
     for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
     return (ax + bu) + Cv[i];
   }
+  // Rows in order, their multipliers loaded ROWS_AHEAD at a time before the first of them is used.
+  static constexpr int ROWS_AHEAD = 1;   // measured: more rows ahead change nothing (the row loop is bound by its arithmetic)
+  template <class F>
+  __device__ static __forceinline__ void for_rows(const KArgs& a, const double* lam, size_t ls, F&& f) {
+    for (int i0 = 0; i0 < a.C; i0 += ROWS_AHEAD) {
+      double l[ROWS_AHEAD];
+#pragma unroll
+      for (int q = 0; q < ROWS_AHEAD; ++q) l[q] = (i0 + q < a.C) ? lam[(size_t)(i0 + q) * ls] : 0.0;
+#pragma unroll
+      for (int q = 0; q < ROWS_AHEAD; ++q)
+        if (i0 + q < a.C) f(i0 + q, l[q]);
+    }
+  }
   __device__ static double cost(const KArgs& a, ctab Q, ctab R, ctab tab,
                                 const double* x, const double* u, const double* g,
                                 const double* lam, size_t ls, double mu) {
@@ -523,13 +540,12 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
     double sc = a.qdiag ? quad_form_diag<N>(e, Q) : quad_form<N>(e, Q);
     double cc = quad_form<M>(u, R);
     double pp = 0.0, ll = 0.0;
-    for (int i = 0; i < a.C; ++i) {
-      double l = lam[i * ls];
+    for_rows(a, lam, ls, [&](int i, double l) {
       double f = l - mu * cval(a, tab, x, u, i);
       double lp = a.eq ? f : fmin(f, 0.0);          // constraints.py:61-62
       pp += lp * lp;
       ll += l * l;
-    }
+    });
     return sc + cc + 0.5 / mu * (pp - ll);
   }
   __device__ static void quadratize(const KArgs& a, ctab Q, ctab R, ctab tab,
@@ -551,8 +567,8 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
     for (int i = 0; i < M; ++i)
 #pragma unroll
       for (int j = 0; j < M; ++j) hu[i][j] = 0.0;
-    for (int i = 0; i < a.C; ++i) {
-      double f = lam[i * ls] - mu * cval(a, tab, x, u, i);
+    for_rows(a, lam, ls, [&](int i, double l) {
+      double f = l - mu * cval(a, tab, x, u, i);
       double lp = a.eq ? f : fmin(f, 0.0);          // constraints.py:70-73, 91-94
       double pj = a.eq ? 1.0 : ((f > 0.0) ? 0.0 : 1.0);
       double pa[N], pb[M];
@@ -568,7 +584,7 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
       for (int p = 0; p < M; ++p)
 #pragma unroll
         for (int q = 0; q < M; ++q) hu[p][q] += pb[p] * pb[q];
-    }
+    });
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       double s = 0.0;
@@ -661,6 +677,64 @@ struct NewAlOps {
     }
     return Cv[i];
   }
+  // One row of a node as the loops below see it: its multiplier and (RECT) its overlay entries, loaded ahead.
+  struct Row { double l, sgn, cn; };
+  // Rows in order, the multipliers (and overlay entries) of ROWS_AHEAD of them loaded before the first is used.
+#ifdef ALILQR_EXP_ROWS_AHEAD
+  static constexpr int ROWS_AHEAD = ALILQR_EXP_ROWS_AHEAD;
+#else
+  static constexpr int ROWS_AHEAD = 1;   // measured: 4 or 8 rows ahead change nothing (the row loop is bound by its arithmetic) and cost registers
+#endif
+  template <class F>
+  __device__ static __forceinline__ void for_rows(const KArgs& a, const double* lam, size_t ls, F&& f) {
+    for (int i0 = 0; i0 < a.C; i0 += ROWS_AHEAD) {
+      Row r[ROWS_AHEAD];
+#pragma unroll
+      for (int q = 0; q < ROWS_AHEAD; ++q) {
+        const bool in = i0 + q < a.C;
+        r[q].l = in ? lam[(size_t)(i0 + q) * ls] : 0.0;
+        r[q].sgn = (RECT && in) ? lam[(size_t)(a.C + i0 + q) * ls] : 0.0;
+        r[q].cn = (RECT && in) ? lam[(size_t)(2 * a.C + i0 + q) * ls] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < ROWS_AHEAD; ++q)
+        if (i0 + q < a.C) f(i0 + q, r[q]);
+    }
+  }
+  // the row-loaded forms of a_ij / c_i / cval / par_cval (same arithmetic)
+  __device__ static __forceinline__ double a_ij(ctab A, const Row& r, int i, int j) {
+    if (RECT) {
+      if (r.sgn != 0.0) return (j == 1) ? r.sgn : 0.0;
+    }
+    return A[i * N + j];
+  }
+  __device__ static __forceinline__ double c_i(ctab Cv, const Row& r, int i) {
+    if (RECT) {
+      if (r.sgn != 0.0) return r.cn;
+    }
+    return Cv[i];
+  }
+  __device__ static __forceinline__ double cval(const KArgs& a, ctab tab, const double* x, const double* u, int i, const Row& r) {
+    ctab A = tab, Bm = tab + a.C * N, Cv = tab + a.C * (N + M);
+    double ax = 0.0, bu = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) ax += a_ij(A, r, i, j) * x[j];
+#pragma unroll
+    for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
+    if (QUAD) return ((quad_term(a, tab, x, i) + ax) + bu) + c_i(Cv, r, i);
+    return ax + bu + c_i(Cv, r, i);
+  }
+  __device__ static __forceinline__ double par_cval(const KArgs& a, ctab tab, const double* x, const double* u, int i, const Row& r) {
+    ctab A = tab, Bm = tab + a.C * N, Cv = tab + a.C * (N + M);
+    double ax = 0.0, bu = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) ax += a_ij(A, r, i, j) * x[j];
+#pragma unroll
+    for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
+    double c = ax + bu + c_i(Cv, r, i);
+    if (QUAD) c = c + quad_term(a, tab, x, i);
+    return c;
+  }
   // A x + B u + C (linear_constraints.h:176-181); quadratic tables put x'Qx first in the sum (quadratic_constraints.h:26)
   __device__ static __forceinline__ double cval(const KArgs& a, ctab tab, const double* x, const double* u, int i,
                                                 const double* lam, size_t ls) {
@@ -695,13 +769,13 @@ struct NewAlOps {
 #pragma unroll
     for (int j = 0; j < M; ++j) cc += (R[j * M + j] * u[j]) * u[j];
     double pp = 0.0, ll = 0.0;
-    for (int i = 0; i < a.C; ++i) {
-      double l = lam[i * ls];
-      const double f = l - mu * cval(a, tab, x, u, i, lam, ls);
+    for_rows(a, lam, ls, [&](int i, const Row& r) {
+      const double l = r.l;
+      const double f = l - mu * cval(a, tab, x, u, i, r);
       double lp = a.eq ? f : fmin(f, 0.0);          // constraints.h:520-528
       pp += lp * lp;
       ll += l * l;
-    }
+    });
     return sc + cc + 0.5 / mu * (pp - ll);
   }
   // one column of parallel_cost / parallel_augmented_lagrangian_cost (constraints.h:558-580)
@@ -713,12 +787,12 @@ struct NewAlOps {
     for (int i = 0; i < N; ++i) { double e = x[i] - g[i]; cq += e * (e * Q[i * N + i]); }
 #pragma unroll
     for (int j = 0; j < M; ++j) cr += (R[j * M + j] * u[j]) * u[j];
-    for (int i = 0; i < a.C; ++i) {
-      double l = lam[i * ls];
-      const double f = l - mu * par_cval(a, tab, x, u, i, lam, ls);
+    for_rows(a, lam, ls, [&](int i, const Row& r) {
+      const double l = r.l;
+      const double f = l - mu * par_cval(a, tab, x, u, i, r);
       double pr = a.eq ? f : fmin(f, 0.0);
       al += pr * pr - l * l;
-    }
+    });
     al = 0.5 / mu * al;
     return (cq + cr) + al;
   }
@@ -741,13 +815,13 @@ struct NewAlOps {
     for (int i = 0; i < M; ++i)
 #pragma unroll
       for (int j = 0; j < M; ++j) hu[i][j] = 0.0;
-    for (int i = 0; i < a.C; ++i) {
-      const double fi = lam[i * ls] - mu * cval(a, tab, x, u, i, lam, ls);
+    for_rows(a, lam, ls, [&](int i, const Row& r) {
+      const double fi = r.l - mu * cval(a, tab, x, u, i, r);
       double lp = a.eq ? fi : fmin(fi, 0.0);        // the equality branch works on the factor itself (constraints.h:673-676)
       double on = a.eq ? 1.0 : ((lp >= 0.0) ? 0.0 : 1.0);
       double cx[N], pa[N], pb[M];
 #pragma unroll
-      for (int j = 0; j < N; ++j) cx[j] = a_ij(a, A, lam, ls, i, j);
+      for (int j = 0; j < N; ++j) cx[j] = a_ij(A, r, i, j);
       if (QUAD && ((a.quad_rows >> i) & 1ull)) {
         // c_x row: A_i + 2 Qc_i x ; constraint Hessian 2 Qc_i weighted by the projected multiplier
         // (quadratic_constraints.h:47-55, 86-88; constraints.h:797-802, 1341-1345)
@@ -775,7 +849,7 @@ struct NewAlOps {
       for (int p = 0; p < M; ++p)
 #pragma unroll
         for (int q = 0; q < M; ++q) hu[p][q] += a.eq ? (Bm[i * M + p] * Bm[i * M + q]) : ((mu * pb[p]) * Bm[i * M + q]);
-    }
+    });
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       double s = 0.0;
@@ -972,6 +1046,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   int cur_slot = 0, cur_par = 0;
   int ref_slot = 0;           // slot of the trajectory the running line search started from (cur_slot moves to the winner before a repeat)
   double mu = 1.0, old_cost = 0.0, viol = 0.0, dv_lin = 0.0;
+  double mu_s = 1.0;          // NEW_AL: the solver's own penalty; the nodes' `mu` follows it from the first increase on
   int outer = 0, inner = 0, n_inner = 0, n_trials = 0;
   bool outer_start = false;
   // Each group is a small state machine that advances by at most one linearise + Riccati pass and one roll-out
@@ -1080,7 +1155,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           for (int i = 0; i < C; ++i) r[(size_t)(RL::rl + i) * ES] = 0.0;
           if (RECT) {
             for (int i = 0; i < 2 * C; ++i) r[(size_t)(RL::rl + C + i) * ES] = 0.0;
-            r[(size_t)(RL::rl + 3 * C) * ES] = (double)a.first_row;
+            r[(size_t)(RL::rl + 3 * C) * ES] = (double)(a.first_rows ? a.first_rows[t] : a.first_row);
           }
         }
         // ---- linearised-LQR initial guess (ilqr.py:11-50): every lane of the group
@@ -1202,6 +1277,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           }
         }
         mu = 1.0;
+        mu_s = (NEWAL && a.mu_s_in) ? a.mu_s_in[p] : 1.0;
         cur_slot = 0; cur_par = 0;
         outer = 0; inner = 0; n_inner = 0; n_trials = 0;
         outer_start = true;
@@ -1567,6 +1643,21 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           for (int r = 0; r < M; ++r) uown[r] = unext[r];
         };
         int t = 0;
+#ifdef ALILQR_EXP_SINGLE_REC
+        if constexpr (N > 4) {
+          for (; t < H; ++t) {
+            roll(t, RA, RB);
+#pragma unroll
+            for (int i = 0; i < N; ++i) { RA.x[i] = RB.x[i]; RA.g[i] = RB.g[i]; }
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+              RA.u[j] = RB.u[j]; RA.k[j] = RB.k[j];
+#pragma unroll
+              for (int i = 0; i < N; ++i) RA.K[j][i] = RB.K[j][i];
+            }
+          }
+        }
+#endif
         for (; t + 1 < H; t += 2) {
           roll(t, RA, RB);
           roll(t + 1, RB, RA);
@@ -1896,7 +1987,8 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
             }
             __threadfence_block();
           } else {
-            mu = mu * a.prm.mu_gain;
+            if constexpr (NEWAL) { mu_s = mu_s * a.prm.mu_gain; mu = mu_s; }   // UpdateMu, new_al_ilqr.h:1125-1130
+            else mu = mu * a.prm.mu_gain;
           }
           if (outer >= a.prm.max_outer) { finished = true; flags = ALILQR_FLAG_OUTER_CAP; }
           else outer_start = true;
@@ -1913,7 +2005,13 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         if (a.lam)
           for (int e = gl; e < (H + 1) * C; e += G)
             a.lam[(size_t)p * (H + 1) * C + e] = rec(e / C)[(size_t)(RL::rl + e % C) * ES];
+        if constexpr (RECT) {
+          if (a.overlay_out)
+            for (int e = gl; e < (H + 1) * (2 * C + 1); e += G)
+              a.overlay_out[(size_t)p * (H + 1) * (2 * C + 1) + e] = rec(e / (2 * C + 1))[(size_t)(RL::rl + C + e % (2 * C + 1)) * ES];
+        }
         if (gl == 0) {
+          if (NEWAL && a.mu_s_out) a.mu_s_out[p] = mu_s;
           a.cost[p] = fc;
           if (a.viol) a.viol[p] = viol;
           if (a.mu) a.mu[p] = mu;

@@ -33,6 +33,9 @@ def _mat(a, r, c, what):
     return a.reshape(r, c).copy()
 
 
+PARALLEL_NUM = 5        # columns of the parallel_* calls (constraints.h:73)
+
+
 class _Constraints:
     """Constraints<n, m, c>: multipliers, penalty and the live-row index (constraints_bind.h:14-31)."""
     N = M = C = 0
@@ -85,6 +88,46 @@ class _Constraints:
     def get_constraint_dim(cls):
         return cls.C
 
+    def projection(self, x):
+        """min(x, 0) per entry (constraints.h:365-367): a selection, no arithmetic."""
+        return np.minimum(_vec(x, self.C, "x"), 0.0)
+
+    def projection_jacobian(self, x):
+        """diag(x < 0) (constraints.h:396-404)."""
+        return np.diag((_vec(x, self.C, "x") < 0).astype(np.float64))
+
+    # ---- the table calls run on the GPU (alilqr_constraints_batch), one point or the five columns of the ladder
+    def _eval(self, X, U):
+        """X (P, n), U (P, m) -> dict of cval / par_cval [P, c], jac_x [P, c, n], jac_u [P, c, m]."""
+        P = X.shape[0]
+        desc = capi.make_problem("lat_k" if self.N == 4 else "new_bicycle", "new_al", 1, P, 1.0, 0.1, c=self.C, cons_kind=self.KIND)
+        x = np.zeros((P, 2, self.N)); x[:, 0] = X
+        u = np.zeros((P, 2, self.M)); u[:, 0] = U
+        out = batch.constraints_batch(desc, x, u, self.table())
+        return {k: v.cpu().numpy()[:, 0] for k, v in out.items()}
+
+    def constraints(self, x, u):
+        """c(x, u)  (linear_constraints.h:176-181, quadratic_constraints.h:15-27)."""
+        return self._eval(_vec(x, self.N, "x")[None], _vec(u, self.M, "u")[None])["cval"][0]
+
+    def parallel_constraints(self, x, u):
+        """c of PARALLEL_NUM = 5 points at once, one per column (linear_constraints.h:218-224,
+        quadratic_constraints.h:29-45)."""
+        X, U = _mat(x, self.N, PARALLEL_NUM, "x"), _mat(u, self.M, PARALLEL_NUM, "u")
+        return np.ascontiguousarray(self._eval(X.T, U.T)["par_cval"].T)
+
+    def constraints_jacobian(self, x=None, u=None):
+        """(c_x, c_u) at (x, u)  (linear_constraints.h:260-265: A, B; quadratic_constraints.h:47-55: A + 2 x'Q_i)."""
+        x = np.zeros(self.N) if x is None else x
+        u = np.zeros(self.M) if u is None else u
+        o = self._eval(_vec(x, self.N, "x")[None], _vec(u, self.M, "u")[None])
+        return o["jac_x"][0], o["jac_u"][0]
+
+    def constraints_hessian(self, x=None, u=None):
+        """(h_xx[c], h_uu[c], h_xu[c]): zero for linear tables (linear_constraints.h:303-328)."""
+        n, m = self.N, self.M
+        return [np.zeros((n, n))] * self.C, [np.zeros((m, m))] * self.C, [np.zeros((n, m))] * self.C
+
     def set_current_constraints_index(self, i):
         self._index = int(i)
 
@@ -109,7 +152,8 @@ class _LinearConstraints(_Constraints):
         self.B = _mat(B, self.C, self.M, "B")
         self.Cv = _vec(C, self.C, "C")
 
-    def constraints_jacobian(self):
+    def constraints_jacobian(self, x=None, u=None):
+        """(A, B): the stored matrices, whatever the point (linear_constraints.h:260-265); nothing is computed."""
         return self.A.copy(), self.B.copy()
 
 
@@ -148,6 +192,7 @@ class _QuadraticConstraints(_Constraints):
         return capi.pack_quadratic(self.Qc, self.A, self.B, self.Cv)
 
     def constraints_hessian(self, x=None, u=None):
+        """(2 Q_i, 0, 0)  (quadratic_constraints.h:66-90); doubling is exact."""
         n, m = self.N, self.M
         return [2.0 * q for q in self.Qc], [np.zeros((m, m))] * self.C, [np.zeros((n, m))] * self.C
 
@@ -164,6 +209,13 @@ def _box(n, m):
     return type(f"BoxConstraints{n}_{m}", (_BoxConstraints,), dict(N=n, M=m, C=2 * (n + m)))
 
 
+def _base(n, m, c):
+    return type(f"Constraints{n}_{m}_{c}", (_Constraints,), dict(N=n, M=m, C=c))
+
+
+# the abstract bases the module also exports (ilqr_pybind.cc:39-47): multipliers, penalty, projection, row index
+Constraints6_2_16, Constraints6_2_5 = _base(6, 2, 16), _base(6, 2, 5)
+Constraints4_1_10, Constraints4_1_6, Constraints4_1_3 = _base(4, 1, 10), _base(4, 1, 6), _base(4, 1, 3)
 LinearConstraints6_2_16 = _linear(6, 2, 16)
 LinearConstraints4_1_10 = _linear(4, 1, 10)
 LinearConstraints4_1_6 = _linear(4, 1, 6)
@@ -289,6 +341,9 @@ def _lat_node(cons_cls):
                 dict(MODEL="lat_k", N=4, M=1, CONSTRAINTS=cons_cls, __init__=__init__))
 
 
+# the abstract node bases the module also exports (ilqr_pybind.cc:63-65): no constructor, like the pybind classes
+ILQRNode6_2 = type("ILQRNode6_2", (_Node,), dict(N=6, M=2))
+ILQRNode4_1 = type("ILQRNode4_1", (_Node,), dict(N=4, M=1))
 NewBicycleNodeBoxConstraints6_2 = _bicycle_node(BoxConstraints6_2)
 NewBicycleNodeLinearConstraints6_2_16 = _bicycle_node(LinearConstraints6_2_16)
 NewLatBicycleNodeLinearConstraints4_1_6 = _lat_node(LinearConstraints4_1_6)
@@ -318,6 +373,7 @@ class _NewALILQR:
         self._x = np.zeros((self.N, self.horizon + 1))
         self._u = np.zeros((self.M, self.horizon))
         self.last_status = None
+        self._mu_solver = 1.0        # mu_ of the solver object: survives optimize() calls (new_al_ilqr.h:1125-1130)
 
     def _describe(self, B, max_outer_iter, max_inner_iter, max_violation):
         nodes = self.ilqr_nodes
@@ -346,12 +402,15 @@ class _NewALILQR:
         if x0.ndim != 2 or x0.shape[1] != self.N:
             raise TypeError("x0 must be [B, n]")
         desc, goals, Q, R, T = self._describe(x0.shape[0], max_outer_iter, max_inner_iter, max_violation)
-        # every node starts from the row index its constraint object was given (set_current_constraints_index)
-        first_row = self.ilqr_nodes[0].constraints_obj.get_current_constraints_index()
-        if any(nd.constraints_obj.get_current_constraints_index() != first_row for nd in self.ilqr_nodes):
+        # every node starts from the row index its constraint object holds (set_current_constraints_index, or what
+        # the rectangle activation of an earlier optimize() left there)
+        rows = [nd.constraints_obj.get_current_constraints_index() for nd in self.ilqr_nodes]
+        rect = bool(self.left_obs or self.right_obs)
+        if not rect and any(r != rows[0] for r in rows):
             raise ValueError("the constraint row index must be the same on every node of a trajectory")
         return batch.solve_batch(desc, x0, goals, Q, R, T, device=device, left_obs=self.left_obs,
-                                 right_obs=self.right_obs, first_row=first_row)
+                                 right_obs=self.right_obs, first_row=rows[0], first_rows=rows if rect else None,
+                                 overlay=rect, mu_solver=self._mu_solver)
 
     def optimize(self, max_outer_iter, max_inner_iter, max_violation):
         out = {k: v.cpu().numpy() for k, v in
@@ -361,6 +420,18 @@ class _NewALILQR:
         for t, nd in enumerate(self.ilqr_nodes):
             nd.constraints_obj.lambda_ = out["lam"][0, t]
             nd.constraints_obj.mu = out["mu"][0]
+        self._mu_solver = float(out["mu_solver"][0])
+        if "overlay" in out:
+            # UpdateConstraints mutates the nodes' own tables and row indices, and they stay that way
+            # (linear_constraints.h:360-373, quadratic_constraints.h:57-64)
+            c = self.ilqr_nodes[0].constraints_obj.C
+            for t, nd in enumerate(self.ilqr_nodes):
+                ov = out["overlay"][0, t]
+                for i in np.nonzero(ov[:c])[0]:
+                    nd.constraints_obj.A[i, :] = 0.0
+                    nd.constraints_obj.A[i, 1] = ov[i]
+                    nd.constraints_obj.Cv[i] = ov[c + i]
+                nd.constraints_obj.set_current_constraints_index(int(ov[2 * c]))
         self.last_status = dict(inner=int(out["status"][0, 0]), outer=int(out["status"][0, 1]),
                                 flags=int(out["status"][0, 2]), rollouts=int(out["status"][0, 3]),
                                 cost=float(out["cost"][0]), violation=float(out["viol"][0]))

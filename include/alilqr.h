@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ALILQR_ABI_VERSION 4
+#define ALILQR_ABI_VERSION 5
 
 /* ---- vehicle model (node type) ------------------------------------------
  * LAT      4 states / 1 control   cilqr/lat_bicycle_node.py:4-91
@@ -230,6 +230,19 @@ typedef struct alilqr_extras {
   int32_t* trace_trials;     /* [B][trace_cap] or NULL */
   int32_t trace_cap;         /* entries per problem */
   int32_t reserved2;         /* 0 */
+  /* State a NewALILQR object carries from one optimize() call into the next (NEW_AL only; all optional).
+   * mu_solver_in / mu_solver_out [B]: the solver's own penalty mu_ (new_al_ilqr.h:1125-1130).  optimize() resets the
+   *   nodes' penalty to 1 (linearizedInitialGuess, :692-695) but not mu_, so the first penalty increase of a later
+   *   call sets the nodes to (mu_ left by the earlier calls) x gain.  NULL in: 1.
+   * first_rows [H+1]: the row index each node's table starts from (overrides first_row); after a solve with
+   *   rectangle obstacles the nodes of the reference hold different indices.
+   * overlay_out [B][H+1][2c+1]: per node, what UpdateConstraints wrote into its table (linear_constraints.h:360-373):
+   *   c row signs (0: row untouched; -1 / +1: the row became  sign * y + B_i u + C'_i <= 0), c constants C'_i, and
+   *   the node's final row index. */
+  const double* mu_solver_in;
+  double* mu_solver_out;
+  const int32_t* first_rows;
+  double* overlay_out;
 } alilqr_extras;
 
 /* alilqr_solve_batch with the optional inputs above (ex may be NULL). */

@@ -540,6 +540,7 @@ static double compute_total_cost(py_solver* s) {           /* ilqr.py:52-56 */
 _Thread_local const double* or_u_offset = NULL;
 _Thread_local const alilqr_extras* or_extras = NULL;
 _Thread_local double or_min_margin = 1.0;
+_Thread_local int or_problem = 0;
 static double* or_margin_out = NULL;      /* [B], set by oracle_set_margin_out: where batch solves record their margins */
 
 /* Ask the following oracle_solve_batch* calls to record every solve's decision margin in out[B] (NULL: stop). */
@@ -877,6 +878,7 @@ int32_t oracle_solve_batch_ex(const alilqr_problem* p,
     const double* g = goals + ((p->goal_batch > 1) ? (size_t)b * xs : 0);
     or_u_offset = (ex && ex->u_offset) ? ex->u_offset + (size_t)b * us : NULL;
     or_extras = ex;
+    or_problem = b;
     or_min_margin = 1.0;
     int r = oracle_solve(p, x0 + (size_t)b * n, g, Q, R, cons,
                          x_out ? x_out + b * xs : NULL, u_out ? u_out + b * us : NULL,
@@ -887,6 +889,7 @@ int32_t oracle_solve_batch_ex(const alilqr_problem* p,
                          status ? status + (size_t)b * ALILQR_STATUS_WORDS : NULL, NULL);
     or_u_offset = NULL;
     or_extras = NULL;
+    or_problem = 0;
     if (or_margin_out) or_margin_out[b] = or_min_margin;
     if (r != 0) rc = r;
   }

@@ -371,7 +371,7 @@ static void nw_node_init(nw_node* nd, const alilqr_problem* p, int t,
   memcpy(nd->Cown, b + c * n + c * m, sizeof(double) * c);
   nd->A = nd->Aown; nd->B = b + c * n; nd->C = nd->Cown;
   nd->Qc = quad ? b + c * n + c * m + c : NULL;
-  nd->cur_index = or_extras ? or_extras->first_row : 0;
+  nd->cur_index = or_extras ? ((or_extras->first_rows) ? or_extras->first_rows[t] : or_extras->first_row) : 0;
   memcpy(nd->goal, goals + (size_t)t * n, sizeof(double) * n);
   nd->mu = 1.0;
 }
@@ -671,7 +671,9 @@ int32_t or_new_solve(const alilqr_problem* p,
   size_t xs = (size_t)(H + 1) * n, us = (size_t)H * m, nn = (size_t)n * n;
   nw_solver s;
   memset(&s, 0, sizeof(s));
-  s.p = p; s.H = H; s.n = n; s.m = m; s.mu = 1.0;
+  s.p = p; s.H = H; s.n = n; s.m = m;
+  /* the solver's own penalty survives from one optimize() to the next (new_al_ilqr.h:1125-1130; only the nodes are reset) */
+  s.mu = (or_extras && or_extras->mu_solver_in) ? or_extras->mu_solver_in[or_problem] : 1.0;
   s.nodes = (nw_node*)malloc(sizeof(nw_node) * (H + 1));
   for (int t = 0; t <= H; ++t) nw_node_init(&s.nodes[t], p, t, goals, Q, R, cons);
   size_t nm = (size_t)n * m, mm = (size_t)m * m, Hn = (size_t)H;
@@ -744,6 +746,24 @@ int32_t or_new_solve(const alilqr_problem* p,
   if (mu) *mu = s.nodes[0].mu;
   if (lam) for (int t = 0; t <= H; ++t) memcpy(lam + (size_t)t * p->c, s.nodes[t].lam, sizeof(double) * p->c);
   if (status) { status[0] = (int32_t)s.n_inner; status[1] = n_outer; status[2] = (int32_t)flags; status[3] = (int32_t)s.n_trials; }
+  if (or_extras && or_extras->mu_solver_out) or_extras->mu_solver_out[or_problem] = s.mu;
+  if (or_extras && or_extras->overlay_out) {
+    /* what UpdateConstraints left in the nodes' own tables, in the layout of alilqr_extras::overlay_out */
+    const int c = p->c, W = 2 * c + 1;
+    const int quad = (p->cons_kind & ALILQR_CONS_QUADRATIC) ? 1 : 0;
+    for (int t = 0; t <= H; ++t) {
+      double* o = or_extras->overlay_out + ((size_t)or_problem * (H + 1) + t) * W;
+      const int tt = (p->table_nodes > 1) ? t : 0;
+      const double* b = cons + (size_t)tt * (c * n + c * m + c + (quad ? c * n * n : 0));
+      for (int i = 0; i < c; ++i) {
+        int changed = (s.nodes[t].Cown[i] != b[c * n + c * m + i]);
+        for (int j = 0; j < n; ++j) changed |= (s.nodes[t].Aown[i * n + j] != b[i * n + j]);
+        o[i] = changed ? s.nodes[t].Aown[i * n + 1] : 0.0;
+        o[c + i] = changed ? s.nodes[t].Cown[i] : 0.0;
+      }
+      o[2 * c] = (double)s.nodes[t].cur_index;
+    }
+  }
   free(buf);
   free(s.nodes);
   return ALILQR_OK;

@@ -40,6 +40,9 @@ extern _Thread_local const double* or_u_offset;
 /* optional inputs (rectangle obstacles, first row index) of the solve running on this thread, or NULL */
 extern _Thread_local const alilqr_extras* or_extras;
 
+/* index of the problem the solve running on this thread has in its batch (per-problem optional inputs / outputs) */
+extern _Thread_local int or_problem;
+
 /* Decision margin of the solve running on this thread: the smallest relative distance, over every accept / reject /
  * stop comparison the solver made, between the two sides of the comparison.  A solve whose margin is far above the
  * arithmetic noise (~1e-15) makes the same decisions in any implementation whose arithmetic differs in the last

@@ -36,7 +36,7 @@ def _p(a):
 
 
 def solve_batch(desc, x0, goals, Q, R, cons, threads=0, extras=True, u_offset=None, left_obs=None, right_obs=None,
-                first_row=0):
+                first_row=0, mu_solver=None, first_rows=None, overlay=False):
     """Run the oracle on a batch; arrays are host numpy float64, C-contiguous.  With ``extras`` the result also holds
     ``margin`` [B]: the smallest relative distance between the two sides of any accept / reject / stop comparison
     the solve made (a solve with a margin at rounding level is decided by rounding)."""
@@ -48,6 +48,18 @@ def solve_batch(desc, x0, goals, Q, R, cons, threads=0, extras=True, u_offset=No
     lo, ro = capi.pack_rectangles(left_obs), capi.pack_rectangles(right_obs)
     ex = capi.Extras(None if uo is None else uo.ctypes.data, lo.ctypes.data if len(lo) else None,
                      ro.ctypes.data if len(ro) else None, len(lo), len(ro), int(first_row), 0)
+    if desc.mode == capi.MODES["new_al"]:
+        out["mu_solver"] = np.ones(B)
+        ex.mu_solver_out = out["mu_solver"].ctypes.data
+        if mu_solver is not None:
+            ms = np.ascontiguousarray(np.broadcast_to(np.asarray(mu_solver, dtype=np.float64), (B,)))
+            ex.mu_solver_in = ms.ctypes.data
+    if first_rows is not None:
+        fr = np.ascontiguousarray(first_rows, dtype=np.int32)
+        ex.first_rows = fr.ctypes.data
+    if overlay:
+        out["overlay"] = np.zeros((B, H + 1, 2 * c + 1))
+        ex.overlay_out = out["overlay"].ctypes.data
     margin = np.ones(B) if extras else None
     lib().oracle_set_margin_out(_p(margin))
     rc = lib().oracle_solve_batch_ex(C.byref(desc), *[_p(a) for a in args], C.byref(ex),

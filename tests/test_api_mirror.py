@@ -191,3 +191,31 @@ def test_pybind_shaped_module_surface(monkeypatch):
     assert desc.prm.viol_stop == 1e-3 and desc.prm.viol_lambda == 5e-3 and desc.prm.mu_gain == 100.0
     with pytest.raises(TypeError):
         ip.NewALILQR6_2([lat] * 5, np.zeros(6))
+
+
+def test_pybind_module_exports_every_name_of_the_reference_module(monkeypatch):
+    """The class names bound in al_ilqr_cpp/ilqr_pybind.cc:39-79, abstract bases included, and the call surface of the
+    constraint classes (constraints_bind.h:14-93)."""
+    import os
+    import sys
+    monkeypatch.syspath_prepend(os.path.join(os.path.dirname(capi.__file__), "compat"))
+    sys.modules.pop("ilqr_pybind", None)
+    import ilqr_pybind as ip
+    for name in ("Constraints6_2_16", "Constraints6_2_5", "Constraints4_1_10", "Constraints4_1_6", "Constraints4_1_3",
+                 "LinearConstraints6_2_16", "LinearConstraints4_1_10", "LinearConstraints4_1_6", "BoxConstraints6_2",
+                 "BoxConstraints4_1", "QuadraticConstraints6_2_5", "QuadraticConstraints4_1_3", "ILQRNode6_2", "ILQRNode4_1",
+                 "NewBicycleNodeBoxConstraints6_2", "NewBicycleNodeQuadraticConstraints6_2_5",
+                 "NewLatBicycleNodeQuadraticConstraints4_1_3", "NewLatBicycleNodeLinearConstraints4_1_6",
+                 "NewALILQR6_2", "NewALILQR4_1"):
+        assert hasattr(ip, name), name
+    assert ip.Constraints6_2_16.get_constraint_dim() == 16 and ip.ILQRNode4_1.get_state_dim() == 4
+    for cls in (ip.LinearConstraints4_1_6, ip.BoxConstraints6_2, ip.QuadraticConstraints4_1_3):
+        for method in ("constraints", "parallel_constraints", "constraints_jacobian", "constraints_hessian", "projection",
+                       "projection_jacobian", "update_mu", "set_current_constraints_index", "get_current_constraints_index"):
+            assert callable(getattr(cls, method)), (cls.__name__, method)
+    lin = ip.LinearConstraints4_1_6(np.zeros((6, 4)), np.zeros((6, 1)), np.zeros(6))
+    v = np.array([1.0, -2.0, 0.0, 3.0, -0.5, -0.0])
+    assert np.array_equal(lin.projection(v), [0.0, -2.0, 0.0, 0.0, -0.5, -0.0])                 # x.cwiseMin(0)
+    assert np.array_equal(lin.projection_jacobian(v), np.diag([0.0, 1.0, 0.0, 0.0, 1.0, 0.0]))   # diag(x < 0)
+    hxx, huu, hxu = lin.constraints_hessian(np.zeros(4), np.zeros(1))
+    assert len(hxx) == 6 and hxx[0].shape == (4, 4) and huu[0].shape == (1, 1) and hxu[0].shape == (4, 1) and not hxx[0].any()

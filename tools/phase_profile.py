@@ -31,10 +31,15 @@ def main():
     B = int(os.environ.get("B", "4096"))
     workloads = {"lat_legacy": lambda: problems.lat_legacy(B, 50, seed=0),
                  "dyn_legacy_h100": lambda: problems.full_legacy("dyn", B, 100, 2),
-                 "fast_box": lambda: problems.fast_box(B), "new_al_box6": lambda: problems.new_al_box(B)}
+                 "fast_box": lambda: problems.fast_box(B), "new_al_box6": lambda: problems.new_al_box(B),
+                 "fast_box_linear_h100": lambda: problems.fast_box_linear(B), "kin_rect": lambda: problems.kin_rect(B),
+                 "new_al_circle6": lambda: problems.new_al_circle(B), "kin_linear": lambda: problems.kin_linear(B)}
     wl = os.environ.get("WORKLOAD", "lat_legacy")
-    desc, x0, goals, Q, R, cons = workloads[wl]()
-    s = batch.BatchSolver(desc, x0, goals, Q, R, cons)
+    prob, kw = workloads[wl](), {}
+    if isinstance(prob[0], tuple):
+        prob, kw = prob
+    desc = prob[0]
+    s = batch.BatchSolver(*prob, **kw)
     s.run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); o = s.run(); e1.record(); torch.cuda.synchronize()
