@@ -6,6 +6,10 @@
 #pragma once
 #include "solver.hpp"
 
+#ifndef ALILQR_NO_LDS_UCUM
+#define ALILQR_NO_LDS_UCUM 0   // development builds: 1 keeps the accumulated controls in HBM
+#endif
+
 namespace alilqr {
 
 enum { LAUNCH_OK = 0, LAUNCH_BAD_WIDTH = 1, LAUNCH_FAILED = 2 };
@@ -33,10 +37,24 @@ inline int launch_family(const KArgs& ka, int G, int waves, hipStream_t st, int 
     const int mode = no_lds ? 0 : legacy_lds_mode(MDx::N, G, ka.H, E);
     const size_t lds = (size_t)(64 / G) * (ka.H + 1) * E * sizeof(double);
     if (mode != 0) {
-      if (G == 32) hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32, true>), grid, block, lds, st, ka);
-      else if (G == 16) hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 16, true>), grid, block, lds, st, ka);
+      if (G == 32) {
+        // the accumulated controls of the open-loop trials 3 .. ntrials share the records' LDS bytes when a wave's two
+        // groups fit their share of the CU's LDS with them
+        int ntrials = 0;
+        for (double al = 1.0; al > ka.prm.alpha_min && ntrials < 64; al = al / 2.0) ++ntrials;
+        const int cols = ntrials > 2 ? ntrials - 2 : 0;
+        const size_t both = 2 * lds_group_doubles(ka.H, E, cols * MDx::M) * sizeof(double);
+        const size_t share = (MDx::N <= 4) ? 160 * 1024 / 8 : 160 * 1024 / 4;
+        if (both <= share && !ALILQR_NO_LDS_UCUM) {
+          KArgs k2 = ka;
+          k2.uc_cols = cols;
+          hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32, 2>), grid, block, both, st, k2);
+        } else {
+          hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32, 1>), grid, block, lds, st, ka);
+        }
+      } else if (G == 16) hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 16, 1>), grid, block, lds, st, ka);
       else {
-        if constexpr (MDx::N <= 4) hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 8, true, 1>), grid, block, lds, st, ka);
+        if constexpr (MDx::N <= 4) hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 8, 1, 1>), grid, block, lds, st, ka);
         else return LAUNCH_BAD_WIDTH;
       }
       return hipGetLastError() == hipSuccess ? LAUNCH_OK : LAUNCH_FAILED;

@@ -77,8 +77,16 @@ __constant__ const double kLitR[1] = {50.0};
 __constant__ const double kLitB[10] = {-1000, -1000, -2 * 3.141592653589793, -10.0, 1000, 1000, 2 * 3.141592653589793, 10.0, -0.1, 0.1};
 #endif
 
+// doubles of one group's share of the LDS pool: its H+1 linearisation records of rec doubles, or (later in the same
+// iteration, in the same bytes) uc doubles of accumulated controls per step
+__host__ __device__ inline size_t lds_group_doubles(int H, int rec, int uc) {
+  const size_t lin = (size_t)(H + 1) * rec, ucd = (size_t)H * uc;
+  return lin > ucd ? lin : ucd;
+}
+
 struct KArgs {
   int B, NG, H, C, goal_batch, table_nodes;
+  int uc_cols;                // LEGACY with the accumulated controls in LDS: open-loop trials kept there (3 .. ntrials)
   int qdiag;                  // every Q table is diagonal (set in the kernel prologue)
   int eq;                     // equality table: no projection of lambda - mu c (ALILQR_CONS_EQUALITY)
   int quad;                   // constraint tables carry per-row quadratic terms (NEW_AL, ALILQR_CONS_QUADRATIC)
@@ -970,7 +978,10 @@ struct FxxOf<MD, true> {
 
 // MINW: waves per SIMD the instantiation is compiled for (0: 2 for the 4-state models, 1 for the 6-state ones).
 // One wave per SIMD gives a wave 512 registers and a 40 KB share of the LDS.
-template <int MODEL, int MODE, int G, bool LDSLIN = false, int MINW = 0>
+// LDSLIN: 0 the linearisation records live in the groups' blocks in HBM; 1 in LDS; 2 (LEGACY) in LDS, and the same
+// LDS bytes hold the accumulated controls of the open-loop line-search trials afterwards: the records are dead once
+// the Riccati sweep has read them, the controls are written after it and dead when the line search ends.
+template <int MODEL, int MODE, int G, int LDSLIN = 0, int MINW = 0>
 __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1))) void solve_kernel(KArgs a) {
   using MD = Model<MODEL>;
   using OPS = NodeOps<MODEL, MODE>;
@@ -979,6 +990,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   constexpr int N = MD::N, M = MD::M;
   constexpr bool LEGACY = (MODE == ALILQR_MODE_LEGACY);
   constexpr bool PACK = LEGACY && LDSLIN && (G < 32);  // many groups per wave share the wave's LDS: packed records
+  constexpr bool LDSUC = LEGACY && (LDSLIN == 2);      // accumulated controls of trials 3 .. ntrials in LDS too
   using NR = NodeRec<MD, MODE, PACK>;
   constexpr bool NEWAL = is_new_al(MODE);
   constexpr bool QUAD = is_quad(MODE);
@@ -1008,7 +1020,9 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   // sequential Riccati sweep then reads them with LDS latency and they cause no memory traffic), else in the
   // group's block in HBM.
   extern __shared__ double lds_pool[];
-  double* const linb = LDSLIN ? lds_pool + (size_t)(lane / G) * (H + 1) * NR::E : blk + (size_t)(H + 1) * RS * ES;
+  // doubles of a group's share of the pool (the host sizes the launch with the same expression: lds_group_doubles)
+  const size_t PGS = lds_group_doubles(H, NR::E, LDSUC ? a.uc_cols * M : 0);
+  double* const linb = LDSLIN ? lds_pool + (size_t)(lane / G) * PGS : blk + (size_t)(H + 1) * RS * ES;
 
   double* const trj = a.trj;
   const int cw = LEGACY ? (2 * N + 2 * M) : C * (N + M + 1) + (QUAD ? C * N * N : 0);   // doubles per constraint table
@@ -1568,7 +1582,8 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
       // roll out one trial.  kind 0: closed loop, step alpha (Python generations: (u + alpha k) + K dx;
       // C++ generation: u + (K dx + alpha k)); kind 1: LEGACY open loop on the accumulated controls of
       // lane `ul`; kind 2: one column of the C++ generation's five-wide ladder (no angle wrap, (u + K dx) + k alpha)
-      auto rollout = [&](const Tgt& tg, bool valid, int kind, double alpha, const double* ucol, size_t ucs, int sslot) -> double {
+      // fly2 (accumulated controls in LDS): the lane runs trial 2, whose controls u + k / 2 are formed from the record
+      auto rollout = [&](const Tgt& tg, bool valid, int kind, double alpha, const double* ucol, size_t ucs, int sslot, bool fly2 = false) -> double {
         double J = 0.0;
         double x[N];
         const double mu = tg.mu;                       // shadows the group's own penalty
@@ -1594,16 +1609,24 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         }
         double uown[M];
 #pragma unroll
-        for (int r = 0; r < M; ++r) uown[r] = (LEGACY && kind == 1 && valid) ? ucol[(size_t)r * ucs] : 0.0;
+        for (int r = 0; r < M; ++r) uown[r] = (LEGACY && kind == 1 && valid && !(LDSUC && fly2)) ? ucol[(size_t)r * ucs] : 0.0;
         auto roll = [&](int t, const RecRegs& R, RecRegs& Rn) {
           load_rec(tg, t + 1, Rn, closed);             // next record in flight while this step computes
           double unext[M];
 #pragma unroll
-          for (int r = 0; r < M; ++r) unext[r] = (LEGACY && kind == 1 && valid && t + 1 < H) ? ucol[(size_t)((t + 1) * M + r) * ucs] : 0.0;
+          for (int r = 0; r < M; ++r)
+            unext[r] = (LEGACY && kind == 1 && valid && !(LDSUC && fly2) && t + 1 < H) ? ucol[(size_t)((t + 1) * M + r) * ucs] : 0.0;
           double u[M];
           if (LEGACY && kind == 1) {
 #pragma unroll
             for (int r = 0; r < M; ++r) u[r] = uown[r];
+            if constexpr (LDSUC) {
+              if (fly2) {
+                const double al2 = 1.0 / 2.0;                                   // the step of trial 2
+#pragma unroll
+                for (int r = 0; r < M; ++r) u[r] = R.u[r] + al2 * R.k[r];      // the first accumulation (ilqr.py:119 after one rejected step)
+              }
+            }
           } else {
 #pragma unroll
             for (int r = 0; r < M; ++r) {
@@ -1643,21 +1666,6 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           for (int r = 0; r < M; ++r) uown[r] = unext[r];
         };
         int t = 0;
-#ifdef ALILQR_EXP_SINGLE_REC
-        if constexpr (N > 4) {
-          for (; t < H; ++t) {
-            roll(t, RA, RB);
-#pragma unroll
-            for (int i = 0; i < N; ++i) { RA.x[i] = RB.x[i]; RA.g[i] = RB.g[i]; }
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-              RA.u[j] = RB.u[j]; RA.k[j] = RB.k[j];
-#pragma unroll
-              for (int i = 0; i < N; ++i) RA.K[j][i] = RB.K[j][i];
-            }
-          }
-        }
-#endif
         for (; t + 1 < H; t += 2) {
           roll(t, RA, RB);
           roll(t + 1, RB, RA);
@@ -1702,9 +1710,13 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         //      All passes go through ONE roll-out call site (the code exists once in the instruction cache).
         const bool act = (p >= 0);
         const size_t gid0 = gid - (size_t)(lane / G);                    // first group of this wave
-        const size_t UCS = (size_t)(ntrials > 1 ? ntrials - 1 : 1);      // open-loop trials 2 .. ntrials
-        const size_t UC = UCS * US;                                      // accumulated controls of one group
-        double* const ucg = a.ucum + gid * UC;                           // [t * M + r][trial - 2]: a step's controls of all trials are contiguous
+        // open-loop trials uc0 .. ntrials keep their accumulated controls: all of them (2 ..) in HBM, or 3 .. in the
+        // group's share of the LDS pool (trial 2 is formed on the fly)
+        const int uc0 = LDSUC ? 3 : 2;
+        const size_t UCS = LDSUC ? (size_t)(a.uc_cols > 0 ? a.uc_cols : 1) : (size_t)(ntrials > 1 ? ntrials - 1 : 1);
+        const size_t UC = LDSUC ? PGS : UCS * US;                        // accumulated controls of one group (LDS: its pool share)
+        double* const ucbase = LDSUC ? lds_pool : a.ucum;
+        double* const ucg = LDSUC ? linb : a.ucum + gid * UC;            // [t * M + r][trial - uc0]: a step's controls of all trials are contiguous
         if (act) {
           // all accumulated controls, nodes in parallel:  u_j = u_{j-1} + 2^-(j-1) k
           for (int t = gl; t < H; t += G) {
@@ -1717,7 +1729,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
               for (int i = 2; i <= ntrials; ++i) {
                 sacc = sacc + al * kf;
                 al = al / 2.0;
-                ucg[(size_t)(t * M + r) * UCS + (i - 2)] = sacc;
+                if (i >= uc0) ucg[(size_t)(t * M + r) * UCS + (i - uc0)] = sacc;
               }
             }
           }
@@ -1766,7 +1778,9 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           (void)ALILQR_CHK(gid_t < NG, 13);
           kind = (trial != 1) ? 1 : 0;
           sslot = !v ? -1 : (pass == PASS_C) ? ((gl == 0) ? SS - 1 : -1) : store_slot(trial);
-          const double J = rollout(tg, v, kind, 1.0, a.ucum + gid_t * UC + (size_t)(trial >= 2 ? trial - 2 : 0), UCS, sslot);
+          const size_t gsel = LDSUC ? (size_t)(gid_t - gid0) : gid_t;    // the target group's controls: its pool share, or its HBM block
+          const double J = rollout(tg, v, kind, 1.0, ucbase + gsel * UC + (size_t)(trial >= uc0 ? trial - uc0 : 0), UCS, sslot,
+                                   LDSUC && trial == 2);
           if (pass == PASS_C) break;
           bool search_over = false;
           if (pass == PASS_A) {
