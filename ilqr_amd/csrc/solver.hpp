@@ -1075,6 +1075,8 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   bool keep_old = false, gate_skip = false, have = false;
   int win_trial = -1, win_lane = -1, r0 = 0, replay_kind = 0;
   int nt0 = 0;                // roll-out count when the running line search started (trace output)
+  bool xo_pend = false;       // the (x, u) pair to return is a trajectory in the slots, not yet copied to x_out / u_out
+  int xo_par = 0, xo_slot = 0;
   // LEGACY: bit t set = some multiplier of node t is not zero (nodes 0 .. 127; longer horizons load them always).
   // A roll-out step reads the node's multipliers only then: they are all zero during the first outer iteration
   // and on most nodes later.
@@ -1292,6 +1294,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         }
         mu = 1.0;
         mu_s = (NEWAL && a.mu_s_in) ? a.mu_s_in[p] : 1.0;
+        xo_pend = false;
         cur_slot = 0; cur_par = 0;
         outer = 0; inner = 0; n_inner = 0; n_trials = 0;
         outer_start = true;
@@ -1943,15 +1946,23 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
                              : (fabs(new_cost - old_cost) < a.prm.inner_tol);
       if (!brk && !keep_old) {
         if (!NEWAL) {
-          // x, u = new_x, new_u : the pair optimize() will return (the C++ generation returns its live arrays)
-          for (int e = gl; e < XS; e += G) a.x_out[(size_t)p * XS + e] = *trj_at(cur_par, e, cur_slot);
-          for (int e = gl; e < US; e += G) a.u_out[(size_t)p * US + e] = *trj_at(cur_par, XS + e, cur_slot);
+          // x, u = new_x, new_u : the pair optimize() will return (the C++ generation returns its live arrays).
+          // Only noted here; the copy is made when the inner loop ends (below).
+          xo_pend = true; xo_par = cur_par; xo_slot = cur_slot;
         }
         old_cost = new_cost;
       }
       bool finished = false;
       unsigned flags = 0;
       if (brk || inner >= a.prm.max_inner) {
+        if (!NEWAL && xo_pend) {
+          // The pair to return is the trajectory of the last iteration that did not end the inner loop.  It sits in
+          // the parity this iteration's candidates were NOT written to (or is the one just accepted), so it is
+          // still whole; the next outer iteration's first line search will overwrite it.
+          for (int e = gl; e < XS; e += G) a.x_out[(size_t)p * XS + e] = *trj_at(xo_par, e, xo_slot);
+          for (int e = gl; e < US; e += G) a.u_out[(size_t)p * US + e] = *trj_at(xo_par, XS + e, xo_slot);
+          xo_pend = false;
+        }
         // constraint violation of the node trajectory, nodes in parallel, combined in node order
         double vtot = OPS::violation_init();
         for (int t0 = 0; t0 <= H; t0 += G) {

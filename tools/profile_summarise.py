@@ -95,6 +95,12 @@ for name, what in (("stall", "wave-cycle breakdown"), ("icache", "instruction ca
         summary["executed_fp64_lane_flops_per_launch"] = fl
         out.append(f"executed fp64 flops per launch, all 64 lanes of every issued instruction counted = {fl:.6g}")
 if out:
+    # which build and workload the counters belong to: bench.py reports them only for that build
+    sys.path.insert(0, ROOT)
+    import bench
+    summary["kernel_source_id"] = bench.kernel_source_id()
+    summary["config"] = "2"
+    summary["command"] = "python3 bench.py --steps 1 --warmup 0 --no-cpu (8 launches of the headline batch: 6 priming, 1 timed, 1 alone; per-launch averages)"
     open(os.path.join(P, tag + "_pmc.txt"), "w").write("\n".join(out) + "\n")
     json.dump(summary, open(os.path.join(P, tag + "_pmc.json"), "w"), indent=1)
 print("\n".join(lines + out))
