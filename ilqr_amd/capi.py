@@ -187,9 +187,11 @@ def load_library():
     return lib
 
 
-def set_tuning(lanes=0, max_waves=0, no_lds=0):
-    """Process-wide tuning / diagnostic overrides of the library (0 = automatic); results do not depend on them."""
-    check(load_library().alilqr_set_tuning(int(lanes), int(max_waves), int(bool(no_lds))), "alilqr_set_tuning")
+def set_tuning(lanes=0, max_waves=0, no_lds=0, dense_rows=0):
+    """Process-wide tuning / diagnostic overrides of the library (0 = automatic); results do not depend on them.
+    ``dense_rows``: evaluate the constraint rows of FAST / NEW_AL tables densely (no box-row short cut)."""
+    check(load_library().alilqr_set_tuning(int(lanes), int(max_waves), int(bool(no_lds)) | (2 if dense_rows else 0)),
+          "alilqr_set_tuning")
 
 
 def release():

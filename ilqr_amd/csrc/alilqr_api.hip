@@ -66,7 +66,7 @@ void* g_last_ws[kMaxDev] = {};   // scratch of the most recent solve on the devi
 std::mutex g_mu;
 
 // Tuning overrides (alilqr_set_tuning): 0 = automatic.
-std::atomic<int> g_opt_lanes{0}, g_opt_max_waves{0}, g_opt_no_lds{0};
+std::atomic<int> g_opt_lanes{0}, g_opt_max_waves{0}, g_opt_no_lds{0}, g_opt_dense_rows{0};
 
 // ---- scratch of the entry point that allocates nothing ----------------------------------------------------------
 // A file-scope device array: every GPU the library runs on holds its own copy until the process ends.  Host code
@@ -199,6 +199,26 @@ int legacy_lin_doubles(const alilqr_problem* p, bool packed) {
     default: return E_OF(ALILQR_MODEL_KIN);
   }
 #undef E_OF
+}
+
+// Does the constraint table start with the rows of a box,  [I; -I; 0; 0] x + [0; 0; I; -I] u + C ?  One wave, lane =
+// row; *out = 2(n+m) if every one of the first 2(n+m) rows is exactly that, else 0 (see BoxRow in solver.hpp).
+__global__ void analyze_rows_kernel(const double* tab, int C, int N, int M, unsigned int* out) {
+  const int i = threadIdx.x, nbox = 2 * (N + M);
+  bool ok = true;
+  if (i < nbox && i < C) {
+    for (int j = 0; j < N; ++j) {
+      const double want = (i < N && j == i) ? 1.0 : ((i >= N && i < 2 * N && j == i - N) ? -1.0 : 0.0);
+      ok &= (tab[(size_t)i * N + j] == want);
+    }
+    for (int j = 0; j < M; ++j) {
+      const int k = i - 2 * N;
+      const double want = (k >= 0 && k < M && j == k) ? 1.0 : ((k >= M && j == k - M) ? -1.0 : 0.0);
+      ok &= (tab[(size_t)C * N + (size_t)i * M + j] == want);
+    }
+  }
+  const bool all_ok = (C >= nbox) && (__ballot(!ok) == 0ull);
+  if (i == 0) *out = all_ok ? (unsigned)nbox : 0u;
 }
 
 // Layout of a solve's scratch.  `cap` > 0 bounds the total: the number of resident waves is reduced until the
@@ -588,6 +608,14 @@ static int32_t solve_impl(const alilqr_problem* p,
   ka.status = status;
   ka.trj = (double*)(base + pl.trj); ka.blk = (double*)(base + pl.blk); ka.ucum = (double*)(base + pl.ucum);
   ka.counter = (unsigned int*)(base + pl.counter);
+  // Linear tables shared by all nodes: is it a box table?  (one word of the counter block, written before the solve)
+  if (p->mode != ALILQR_MODE_LEGACY && p->table_nodes == 1 && !(p->cons_kind & ALILQR_CONS_QUADRATIC) && !rect &&
+      2 * (d.N + d.M) <= 64 && !g_opt_dense_rows.load(std::memory_order_relaxed)) {
+    unsigned int* word = (unsigned int*)(base + pl.counter + 48);
+    hipLaunchKernelGGL(analyze_rows_kernel, dim3(1), dim3(64), 0, st, cons, (int)p->c, (int)d.N, (int)d.M, word);
+    if (hipGetLastError() != hipSuccess) { set_err("row analysis launch failed"); return ALILQR_E_HIP; }
+    ka.box_rows = word;
+  }
   // The problem counter is never reset: a solve starts from the value the scratch's previous solve left, which
   // the host knows exactly - every problem is pulled once and every group makes one failing pull at the end.
   ka.counter_base = *counter_next;
@@ -649,7 +677,8 @@ int32_t alilqr_set_tuning(int32_t lanes, int32_t max_waves, int32_t no_lds) {
     set_err("lanes must be 0 (automatic), 1, 4, 8, 16 or 32"); return ALILQR_E_ARG;
   }
   if (max_waves < 0) { set_err("max_waves must be >= 0"); return ALILQR_E_ARG; }
-  g_opt_lanes.store(lanes); g_opt_max_waves.store(max_waves); g_opt_no_lds.store(no_lds ? 1 : 0);
+  g_opt_lanes.store(lanes); g_opt_max_waves.store(max_waves);
+  g_opt_no_lds.store((no_lds & 1) ? 1 : 0); g_opt_dense_rows.store((no_lds & 2) ? 1 : 0);
   return ALILQR_OK;
 }
 

@@ -77,6 +77,40 @@ __constant__ const double kLitR[1] = {50.0};
 __constant__ const double kLitB[10] = {-1000, -1000, -2 * 3.141592653589793, -10.0, 1000, 1000, 2 * 3.141592653589793, 10.0, -0.1, 0.1};
 #endif
 
+// ---------------------------------------------------------------------------
+// Box tables (FAST / NEW_AL).  The table of BoxConstraints (box_constraints.h:35-78, box_constrains.py:5-32) is
+//     [ I ; -I ; 0 ; 0 ] x + [ 0 ; 0 ; I ; -I ] u + [ -x_max ; x_min ; -u_max ; u_min ]
+// and the dense row product  A_i x + B_i u  is seven multiplications by zero and one by +-1.  A one-wave kernel
+// (analyze_rows_kernel, alilqr_api.hip) checks once per solve whether the first 2(n+m) rows of the table are exactly
+// that; the node code then evaluates those rows as  (0.0 +- z) + C_i  with the column known at compile time.  That is
+// the value of the dense sums  ax = 0.0; ax += A_i0 * x_0; ...  for finite x, u: every other term is +-0, adding +-0
+// changes neither a non-zero sum nor +0, 1.0 * z is z and -1.0 * z is -z.  (A non-finite x_j makes 0 * x_j a NaN in
+// the dense sum: nodes with a non-finite state or control take the dense code.)  Rows behind the box stay dense.
+// ---------------------------------------------------------------------------
+template <int N, int M>
+struct BoxRow {
+  int i;
+  __device__ __forceinline__ constexpr bool is_u() const { return i >= 2 * N; }
+  __device__ __forceinline__ constexpr int col() const { return is_u() ? (i - 2 * N) % M : i % N; }
+  __device__ __forceinline__ constexpr bool neg() const { return is_u() ? (i - 2 * N) >= M : i >= N; }
+  // A_i x + B_i u of the row
+  __device__ __forceinline__ double dot(const double* x, const double* u) const {
+    const double z = is_u() ? u[col()] : x[col()];
+    return neg() ? (0.0 - z) : (0.0 + z);
+  }
+  __device__ __forceinline__ constexpr double sign() const { return neg() ? -1.0 : 1.0; }
+};
+// 0.0 exactly when every entry is finite, NaN otherwise
+template <int N, int M>
+__device__ __forceinline__ bool all_finite(const double* x, const double* u) {
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) s += x[j] - x[j];
+#pragma unroll
+  for (int j = 0; j < M; ++j) s += u[j] - u[j];
+  return s == 0.0;
+}
+
 // doubles of one group's share of the LDS pool: its H+1 linearisation records of rec doubles, or (later in the same
 // iteration, in the same bytes) uc doubles of accumulated controls per step
 __host__ __device__ inline size_t lds_group_doubles(int H, int rec, int uc) {
@@ -87,6 +121,7 @@ __host__ __device__ inline size_t lds_group_doubles(int H, int rec, int uc) {
 struct KArgs {
   int B, NG, H, C, goal_batch, table_nodes;
   int uc_cols;                // LEGACY with the accumulated controls in LDS: open-loop trials kept there (3 .. ntrials)
+  const unsigned int* box_rows;  // FAST / NEW_AL: device word = 2(n+m) when the table starts with the box rows, else 0; or null
   int qdiag;                  // every Q table is diagonal (set in the kernel prologue)
   int eq;                     // equality table: no projection of lambda - mu c (ALILQR_CONS_EQUALITY)
   int quad;                   // constraint tables carry per-row quadratic terms (NEW_AL, ALILQR_CONS_QUADRATIC)
@@ -526,11 +561,19 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
     for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
     return (ax + bu) + Cv[i];
   }
-  // Rows in order, their multipliers loaded ROWS_AHEAD at a time before the first of them is used.
+  static constexpr int NBOX = 2 * (N + M);
+  // does this node evaluate the leading rows of its table as box rows?  (uniform over the wave: one lane with a
+  // non-finite point sends the wave through the dense code)
+  __device__ static __forceinline__ bool boxed(const KArgs& a, const double* x, const double* u) {
+    if (a.box_rows == nullptr) return false;
+    const unsigned int nb = *(const unsigned int __attribute__((address_space(4)))*)a.box_rows;
+    return nb == (unsigned)NBOX && !__any(!all_finite<N, M>(x, u));
+  }
+  // Rows first .. C-1 in order, their multipliers loaded ROWS_AHEAD at a time before the first of them is used.
   static constexpr int ROWS_AHEAD = 1;   // measured: more rows ahead change nothing (the row loop is bound by its arithmetic)
   template <class F>
-  __device__ static __forceinline__ void for_rows(const KArgs& a, const double* lam, size_t ls, F&& f) {
-    for (int i0 = 0; i0 < a.C; i0 += ROWS_AHEAD) {
+  __device__ static __forceinline__ void for_rows(const KArgs& a, const double* lam, size_t ls, F&& f, int first = 0) {
+    for (int i0 = first; i0 < a.C; i0 += ROWS_AHEAD) {
       double l[ROWS_AHEAD];
 #pragma unroll
       for (int q = 0; q < ROWS_AHEAD; ++q) l[q] = (i0 + q < a.C) ? lam[(size_t)(i0 + q) * ls] : 0.0;
@@ -548,12 +591,25 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
     double sc = a.qdiag ? quad_form_diag<N>(e, Q) : quad_form<N>(e, Q);
     double cc = quad_form<M>(u, R);
     double pp = 0.0, ll = 0.0;
+    const bool box = boxed(a, x, u);
+    if (box) {
+      ctab Cv = tab + a.C * (N + M);
+#pragma unroll
+      for (int i = 0; i < NBOX; ++i) {
+        const BoxRow<N, M> row{i};
+        const double l = lam[(size_t)i * ls];
+        double f = l - mu * ((row.dot(x, u) + 0.0) + Cv[i]);
+        double lp = a.eq ? f : fmin(f, 0.0);
+        pp += lp * lp;
+        ll += l * l;
+      }
+    }
     for_rows(a, lam, ls, [&](int i, double l) {
       double f = l - mu * cval(a, tab, x, u, i);
       double lp = a.eq ? f : fmin(f, 0.0);          // constraints.py:61-62
       pp += lp * lp;
       ll += l * l;
-    });
+    }, box ? NBOX : 0);
     return sc + cc + 0.5 / mu * (pp - ll);
   }
   __device__ static void quadratize(const KArgs& a, ctab Q, ctab R, ctab tab,
@@ -575,6 +631,22 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
     for (int i = 0; i < M; ++i)
 #pragma unroll
       for (int j = 0; j < M; ++j) hu[i][j] = 0.0;
+    const bool box = boxed(a, x, u);
+    if (box) {
+      // a box row touches one gradient entry and one diagonal Hessian entry; what the dense code adds to the others
+      // is +-0 (a product with a zero factor)
+      ctab Cv = tab + a.C * (N + M);
+#pragma unroll
+      for (int i = 0; i < NBOX; ++i) {
+        const BoxRow<N, M> row{i};
+        double f = lam[(size_t)i * ls] - mu * ((row.dot(x, u) + 0.0) + Cv[i]);
+        double lp = a.eq ? f : fmin(f, 0.0);
+        double pj = a.eq ? 1.0 : ((f > 0.0) ? 0.0 : 1.0);
+        const double pz = pj * row.sign();
+        if (row.is_u()) { ju[row.col()] += pz * lp; hu[row.col()][row.col()] += pz * pz; }
+        else { jx[row.col()] += pz * lp; hx[row.col()][row.col()] += pz * pz; }
+      }
+    }
     for_rows(a, lam, ls, [&](int i, double l) {
       double f = l - mu * cval(a, tab, x, u, i);
       double lp = a.eq ? f : fmin(f, 0.0);          // constraints.py:70-73, 91-94
@@ -592,7 +664,7 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
       for (int p = 0; p < M; ++p)
 #pragma unroll
         for (int q = 0; q < M; ++q) hu[p][q] += pb[p] * pb[q];
-    });
+    }, box ? NBOX : 0);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       double s = 0.0;
@@ -693,9 +765,17 @@ struct NewAlOps {
 #else
   static constexpr int ROWS_AHEAD = 1;   // measured: 4 or 8 rows ahead change nothing (the row loop is bound by its arithmetic) and cost registers
 #endif
+  static constexpr int NBOX = 2 * (N + M);
+  // does this node evaluate the leading rows of its table as box rows?  (linear tables without rectangle overlay;
+  // uniform over the wave: one lane with a non-finite point sends the wave through the dense code)
+  __device__ static __forceinline__ bool boxed(const KArgs& a, const double* x, const double* u) {
+    if (QUAD || RECT || a.box_rows == nullptr) return false;
+    const unsigned int nb = *(const unsigned int __attribute__((address_space(4)))*)a.box_rows;
+    return nb == (unsigned)NBOX && !__any(!all_finite<N, M>(x, u));
+  }
   template <class F>
-  __device__ static __forceinline__ void for_rows(const KArgs& a, const double* lam, size_t ls, F&& f) {
-    for (int i0 = 0; i0 < a.C; i0 += ROWS_AHEAD) {
+  __device__ static __forceinline__ void for_rows(const KArgs& a, const double* lam, size_t ls, F&& f, int first = 0) {
+    for (int i0 = first; i0 < a.C; i0 += ROWS_AHEAD) {
       Row r[ROWS_AHEAD];
 #pragma unroll
       for (int q = 0; q < ROWS_AHEAD; ++q) {
@@ -777,13 +857,26 @@ struct NewAlOps {
 #pragma unroll
     for (int j = 0; j < M; ++j) cc += (R[j * M + j] * u[j]) * u[j];
     double pp = 0.0, ll = 0.0;
+    const bool box = boxed(a, x, u);
+    if (box) {
+      ctab Cv = tab + a.C * (N + M);
+#pragma unroll
+      for (int i = 0; i < NBOX; ++i) {
+        const BoxRow<N, M> row{i};
+        const double l = lam[(size_t)i * ls];
+        const double f = l - mu * ((row.dot(x, u) + 0.0) + Cv[i]);
+        double lp = a.eq ? f : fmin(f, 0.0);
+        pp += lp * lp;
+        ll += l * l;
+      }
+    }
     for_rows(a, lam, ls, [&](int i, const Row& r) {
       const double l = r.l;
       const double f = l - mu * cval(a, tab, x, u, i, r);
       double lp = a.eq ? f : fmin(f, 0.0);          // constraints.h:520-528
       pp += lp * lp;
       ll += l * l;
-    });
+    }, box ? NBOX : 0);
     return sc + cc + 0.5 / mu * (pp - ll);
   }
   // one column of parallel_cost / parallel_augmented_lagrangian_cost (constraints.h:558-580)
@@ -795,12 +888,24 @@ struct NewAlOps {
     for (int i = 0; i < N; ++i) { double e = x[i] - g[i]; cq += e * (e * Q[i * N + i]); }
 #pragma unroll
     for (int j = 0; j < M; ++j) cr += (R[j * M + j] * u[j]) * u[j];
+    const bool box = boxed(a, x, u);
+    if (box) {
+      ctab Cv = tab + a.C * (N + M);
+#pragma unroll
+      for (int i = 0; i < NBOX; ++i) {
+        const BoxRow<N, M> row{i};
+        const double l = lam[(size_t)i * ls];
+        const double f = l - mu * ((row.dot(x, u) + 0.0) + Cv[i]);
+        double pr = a.eq ? f : fmin(f, 0.0);
+        al += pr * pr - l * l;
+      }
+    }
     for_rows(a, lam, ls, [&](int i, const Row& r) {
       const double l = r.l;
       const double f = l - mu * par_cval(a, tab, x, u, i, r);
       double pr = a.eq ? f : fmin(f, 0.0);
       al += pr * pr - l * l;
-    });
+    }, box ? NBOX : 0);
     al = 0.5 / mu * al;
     return (cq + cr) + al;
   }
@@ -823,6 +928,28 @@ struct NewAlOps {
     for (int i = 0; i < M; ++i)
 #pragma unroll
       for (int j = 0; j < M; ++j) hu[i][j] = 0.0;
+    const bool box = boxed(a, x, u);
+    if (box) {
+      // a box row touches one gradient entry and one diagonal Hessian entry; what the dense code adds to the others
+      // is +-0 (a product with a zero factor)
+      ctab Cv = tab + a.C * (N + M);
+#pragma unroll
+      for (int i = 0; i < NBOX; ++i) {
+        const BoxRow<N, M> row{i};
+        const double fi = lam[(size_t)i * ls] - mu * ((row.dot(x, u) + 0.0) + Cv[i]);
+        double lp = a.eq ? fi : fmin(fi, 0.0);
+        double on = a.eq ? 1.0 : ((lp >= 0.0) ? 0.0 : 1.0);
+        const double s = row.sign();
+        const double pz = on * s;
+        if (row.is_u()) {
+          ju[row.col()] += pz * lp;
+          hu[row.col()][row.col()] += a.eq ? (s * s) : ((mu * pz) * s);
+        } else {
+          jx[row.col()] += pz * lp;
+          hx[row.col()][row.col()] += a.eq ? (s * s) : ((mu * pz) * s);
+        }
+      }
+    }
     for_rows(a, lam, ls, [&](int i, const Row& r) {
       const double fi = r.l - mu * cval(a, tab, x, u, i, r);
       double lp = a.eq ? fi : fmin(fi, 0.0);        // the equality branch works on the factor itself (constraints.h:673-676)
@@ -857,7 +984,7 @@ struct NewAlOps {
       for (int p = 0; p < M; ++p)
 #pragma unroll
         for (int q = 0; q < M; ++q) hu[p][q] += a.eq ? (Bm[i * M + p] * Bm[i * M + q]) : ((mu * pb[p]) * Bm[i * M + q]);
-    });
+    }, box ? NBOX : 0);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       double s = 0.0;

@@ -350,7 +350,8 @@ int64_t alilqr_static_scratch_bytes(void);
  * Tuning / diagnostic overrides of the whole process (no counterpart in the reference); 0 = automatic.
  *   lanes      lanes per problem (1, 4, 8, 16, 32)
  *   max_waves  upper bound of resident waves per solve
- *   no_lds     1: keep the linearisation records in HBM even where they fit in LDS
+ *   no_lds     bit 0: keep the linearisation records (and accumulated controls) in HBM even where they fit in LDS;
+ *              bit 1: evaluate every constraint row of FAST / NEW_AL tables densely (no box-row short cut)
  * Results do not depend on any of them (tests compare the bits).
  */
 int32_t alilqr_set_tuning(int32_t lanes, int32_t max_waves, int32_t no_lds);

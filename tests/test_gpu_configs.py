@@ -126,3 +126,39 @@ def test_rectangle_obstacle_activation_matches_oracle(name, lanes, tuning):
     same = to_np(batch.solve_batch(*prob, left_obs=far, first_row=kw["first_row"]))
     for k in ("x", "u", "cost", "status"):
         assert np.array_equal(same[k], free[k]), k
+
+
+@pytest.mark.parametrize("name", ["fast_box", "fast_box_linear", "new_al_box6", "new_al_box6_active", "new_al_lat4", "kin_linear",
+                                  "lat_rect", "kin_rect", "fast_equality"])
+def test_single_entry_row_codes_do_not_change_bits(name, tuning):
+    """Box bounds and half-planes are rows with one entry; the kernels evaluate such rows from a per-row code instead
+    of the dense product.  Same bits as the dense rows (the dense_rows tuning override), diverging solves included."""
+    kw = {}
+    if name == "fast_box":
+        prob = problems.fast_box(24)
+    elif name == "fast_box_linear":
+        prob = problems.fast_box_linear(12)
+    elif name == "new_al_box6":
+        prob = problems.new_al_box(24)
+    elif name == "new_al_box6_active":
+        prob = problems.new_al_box(24, y_max=20.0)
+    elif name == "new_al_lat4":
+        prob = problems.new_al_lat(24)
+    elif name == "kin_linear":
+        prob = problems.kin_linear(24)          # a table with dense rows: those keep the dense code
+    elif name == "lat_rect":
+        prob, kw = problems.new_al_lat_rect(16)
+    elif name == "kin_rect":
+        prob, kw = problems.kin_rect(16)
+    else:
+        g = gu.load("fast_equality")
+        prob = gu.problem_from_golden(g)
+    x0 = np.array(prob[1], dtype=np.float64)
+    x0[0, 1] = np.inf if name in ("fast_box", "new_al_box6") else x0[0, 1]      # a non-finite point takes the dense code
+    prob = (prob[0], x0) + tuple(prob[2:])
+    tuning(dense_rows=1)
+    dense = to_np(batch.solve_batch(*prob, **kw))
+    tuning(dense_rows=0)
+    coded = to_np(batch.solve_batch(*prob, **kw))
+    for k in dense:
+        assert np.array_equal(dense[k], coded[k], equal_nan=True), (name, k)
