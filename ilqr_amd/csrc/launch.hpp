@@ -33,8 +33,15 @@ inline int launch_family(const KArgs& ka, int G, int waves, hipStream_t st, int 
   dim3 grid(waves), block(64);
   if constexpr (MODE == ALILQR_MODE_LEGACY) {
     using MDx = Model<MODEL>;
-    const int E = (G == 32) ? NodeRec<MDx, MODE>::E : NodeRec<MDx, MODE, true>::E;     // narrower groups pack their records
-    const int mode = no_lds ? 0 : legacy_lds_mode(MDx::N, G, ka.H, E);
+    int E = (G == 32) ? NodeRec<MDx, MODE>::E : NodeRec<MDx, MODE, true>::E;     // narrower groups pack their records
+    int mode = no_lds ? 0 : legacy_lds_mode(MDx::N, G, ka.H, E);
+    bool packed32 = false;
+    if (G == 32 && mode == 0 && !no_lds && legacy_lds_mode(MDx::N, G, ka.H, NodeRec<MDx, MODE, true>::E) != 0) {
+      // long horizons: the unpacked records of a wave's two groups do not fit its LDS share, the packed ones do
+      E = NodeRec<MDx, MODE, true>::E;
+      mode = legacy_lds_mode(MDx::N, G, ka.H, E);
+      packed32 = true;
+    }
     const size_t lds = (size_t)(64 / G) * (ka.H + 1) * E * sizeof(double);
     if (mode != 0) {
       if (G == 32) {
@@ -45,7 +52,9 @@ inline int launch_family(const KArgs& ka, int G, int waves, hipStream_t st, int 
         const int cols = ntrials > 2 ? ntrials - 2 : 0;
         const size_t both = 2 * lds_group_doubles(ka.H, E, cols * MDx::M) * sizeof(double);
         const size_t share = (MDx::N <= 4) ? 160 * 1024 / 8 : 160 * 1024 / 4;
-        if (both <= share && !ALILQR_NO_LDS_UCUM) {
+        if (packed32) {
+          hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32, 3>), grid, block, lds, st, ka);
+        } else if (both <= share && !ALILQR_NO_LDS_UCUM) {
           KArgs k2 = ka;
           k2.uc_cols = cols;
           hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32, 2>), grid, block, both, st, k2);

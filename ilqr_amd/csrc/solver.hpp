@@ -1107,7 +1107,8 @@ struct FxxOf<MD, true> {
 // One wave per SIMD gives a wave 512 registers and a 40 KB share of the LDS.
 // LDSLIN: 0 the linearisation records live in the groups' blocks in HBM; 1 in LDS; 2 (LEGACY) in LDS, and the same
 // LDS bytes hold the accumulated controls of the open-loop line-search trials afterwards: the records are dead once
-// the Riccati sweep has read them, the controls are written after it and dead when the line search ends.
+// the Riccati sweep has read them, the controls are written after it and dead when the line search ends; 3 (LEGACY,
+// 32 lanes) in LDS in their packed form.
 template <int MODEL, int MODE, int G, int LDSLIN = 0, int MINW = 0>
 __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1))) void solve_kernel(KArgs a) {
   using MD = Model<MODEL>;
@@ -1116,7 +1117,9 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   using RL = RecLayout<MD>;
   constexpr int N = MD::N, M = MD::M;
   constexpr bool LEGACY = (MODE == ALILQR_MODE_LEGACY);
-  constexpr bool PACK = LEGACY && LDSLIN && (G < 32);  // many groups per wave share the wave's LDS: packed records
+  // packed records: where many groups share the wave's LDS, and (LDSLIN == 3) for 32-lane groups whose unpacked
+  // records do not fit (long horizons)
+  constexpr bool PACK = LEGACY && ((LDSLIN && (G < 32)) || LDSLIN == 3);
   constexpr bool LDSUC = LEGACY && (LDSLIN == 2);      // accumulated controls of trials 3 .. ntrials in LDS too
   using NR = NodeRec<MD, MODE, PACK>;
   constexpr bool NEWAL = is_new_al(MODE);

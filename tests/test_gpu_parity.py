@@ -274,7 +274,8 @@ def test_lds_resident_linearisation_records_do_not_change_bits(tuning):
     """The 32-lane LEGACY kernels keep their linearisation records in LDS where they fit; the no_lds tuning override forces
     the HBM path.  Same arithmetic, same bits."""
     outs = []
-    for prob in (problems.lat_legacy(96, 50, seed=31), problems.full_legacy("dyn", 48, 60, 32)):
+    # lateral: records + accumulated controls in LDS; dynamic H = 60: records; dynamic H = 100: packed records
+    for prob in (problems.lat_legacy(96, 50, seed=31), problems.full_legacy("dyn", 48, 60, 32), problems.full_legacy("dyn", 24, 100, 2)):
         tuning(no_lds=0)
         a = to_np(batch.solve_batch(*prob))
         tuning(no_lds=1)
