@@ -1085,6 +1085,9 @@ __host__ __device__ inline size_t block_doubles(int H, int C) {
 #ifndef ALILQR_MINW_N4
 #define ALILQR_MINW_N4 2   // waves per SIMD the 4-state kernels are compiled for (256 registers per lane)
 #endif
+#ifndef ALILQR_MINW_N6
+#define ALILQR_MINW_N6 1   // waves per SIMD the 6-state kernels are compiled for (512 registers per lane)
+#endif
 // trajectory slots per problem and parity: the usual winners + one spare for a repeated roll-out
 template <int MODE>
 struct TrjSlots { static constexpr int SS = (MODE == ALILQR_MODE_LEGACY) ? 4 : 8; };
@@ -1110,7 +1113,7 @@ struct FxxOf<MD, true> {
 // the Riccati sweep has read them, the controls are written after it and dead when the line search ends; 3 (LEGACY,
 // 32 lanes) in LDS in their packed form.
 template <int MODEL, int MODE, int G, int LDSLIN = 0, int MINW = 0>
-__global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : 1))) void solve_kernel(KArgs a) {
+__global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : ALILQR_MINW_N6))) void solve_kernel(KArgs a) {
   using MD = Model<MODEL>;
   using OPS = NodeOps<MODEL, MODE>;
   using LL = LinLayout<MD>;
