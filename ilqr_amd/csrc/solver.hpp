@@ -1729,7 +1729,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         (void)bdoubles;
         (void)ALILQR_CHK(tg.trjp >= trj && tg.trjp + (size_t)SS * T <= trj + NG * 2 * SS * (size_t)T, 7);
         (void)ALILQR_CHK(tg.cur >= trj && tg.cur + T <= trj + NG * 2 * SS * (size_t)T, 8);
-        (void)ALILQR_CHK(!(LEGACY && kind == 1 && valid) || (ucol >= a.ucum && ucol + (size_t)(US - 1) * ucs < a.ucum + NG * (size_t)US * ucs), 9);
+        (void)ALILQR_CHK(!(LEGACY && !LDSUC && kind == 1 && valid) || (ucol >= a.ucum && ucol + (size_t)(US - 1) * ucs < a.ucum + NG * (size_t)US * ucs), 9);
         double* const tout = tg.trjp + (size_t)(sslot >= 0 && sslot < SS ? sslot : 0) * T;
         auto rec = [&](int t) -> double* {
           if (!ALILQR_CHK(t >= 0 && t <= H, 10)) t = 0;
