@@ -31,7 +31,7 @@ constexpr double kTwoPi = 6.283185307179586;
 __device__ __forceinline__ double wrap_py(double a) {
   double t = a + kPi;
   if (t >= 0.0 && t < kTwoPi) return t - kPi;
-  double r = fmod(t, kTwoPi);
+  double r = fmod_far(t, kTwoPi);
   if (r != 0.0) {
     if (r < 0.0) r += kTwoPi;
   } else {
@@ -346,7 +346,7 @@ template <> struct Model<ALILQR_MODEL_DYN_MID> : Full6<ALILQR_MODEL_DYN_MID> {};
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double wrap_c(double a) {
   if (fabs(a) < 3.14159265358979323846) return a;
-  return fmod(a + 3.14159265358979323846, 2 * 3.14159265358979323846) - 3.14159265358979323846;
+  return fmod_far(a + 3.14159265358979323846, 2 * 3.14159265358979323846) - 3.14159265358979323846;
 }
 
 template <>

@@ -11,6 +11,18 @@
 
 namespace alilqr {
 
+// The device library's large-argument paths (Payne-Hanek reduction, the fmod loop) are reached only by diverging
+// solves.  They are calls, not inlined code: inlined at every use they multiplied the code of the roll-out loops and
+// their registers were allocated on the paths that never run them.
+struct SinCos { double s, c; };
+__device__ __noinline__ SinCos sincos_far(double x) {
+  SinCos r;
+  sincos(x, &r.s, &r.c);
+  return r;
+}
+__device__ __noinline__ double tan_far(double x) { return tan(x); }
+__device__ __noinline__ double fmod_far(double x, double y) { return fmod(x, y); }
+
 __device__ __forceinline__ void sincos_kernels(double r, double* s, double* c) {
   const double z = r * r;
   // sin
@@ -37,7 +49,8 @@ __device__ __forceinline__ void sincos_kernels(double r, double* s, double* c) {
 
 __device__ __forceinline__ void sincos_w(double x, double* s, double* c) {
   if (__builtin_expect(!(fabs(x) <= 4.0), 0)) {
-    sincos(x, s, c);
+    const SinCos r = sincos_far(x);
+    *s = r.s; *c = r.c;
     return;
   }
   const double q = rint(x * 6.36619772367581382433e-01);          // nearest multiple of pi/2
@@ -102,7 +115,7 @@ __device__ __forceinline__ double tan_pi(double x) {
 
 __device__ __forceinline__ double tan_w(double x) {
   if (__builtin_expect(fabs(x) < 0.67434, 1)) return tan_poly(x);
-  if (__builtin_expect(!(fabs(x) <= 4.0), 0)) return tan(x);
+  if (__builtin_expect(!(fabs(x) <= 4.0), 0)) return tan_far(x);
   double s, c;
   sincos_w(x, &s, &c);
   return s / c;
