@@ -126,6 +126,8 @@ struct KArgs {
   int eq;                     // equality table: no projection of lambda - mu c (ALILQR_CONS_EQUALITY)
   int quad;                   // constraint tables carry per-row quadratic terms (NEW_AL, ALILQR_CONS_QUADRATIC)
   unsigned long long quad_rows;   // rows whose quadratic matrix is not all zero, over all tables (kernel prologue)
+  int sparse_rows;            // host: the one shared linear table may be searched for all-zero A / B rows
+  unsigned long long azero, bzero;   // NEW_AL: rows whose A (B) entries are all zero (kernel prologue; 0 = none known)
   ModelConst mc;
   alilqr_params prm;
   const double *x0, *goals, *Q, *R, *cons;
@@ -802,23 +804,57 @@ struct NewAlOps {
     }
     return Cv[i];
   }
-  __device__ static __forceinline__ double cval(const KArgs& a, ctab tab, const double* x, const double* u, int i, const Row& r) {
-    ctab A = tab, Bm = tab + a.C * N, Cv = tab + a.C * (N + M);
-    double ax = 0.0, bu = 0.0;
+  // Rows of zeros.  Constraint tables are mostly sparse (the reference's own: control bounds plus a pool of empty rows
+  // that rectangle obstacles fill, test_lat_al_ilqr.cc:52-68).  A_i x of a row whose A entries are all zero is the sum
+  // of N products with zero: +0 for a finite point, NaN otherwise, the same for every such row of a node - it is
+  // formed once per node (ZeroSums) instead of once per row.  A rectangle overlay replaces such a row by  sgn * y:
+  // ((0 + 0 x_0) + sgn x_1) + 0 x_2 ... = (0 + sgn x_1) + the zero products of the other columns.  Same bits as the
+  // dense sums.  Which rows are zero is a property of the table: two bit masks found in the kernel prologue.
+  struct ZeroSums { double xa, x1, ub; };
+  __device__ static __forceinline__ ZeroSums zero_sums(const double* x, const double* u) {
+    ZeroSums z;
+    double sa = 0.0, s1 = 0.0, sb = 0.0;
+    if (!SPARSE) { z.xa = 0.0; z.x1 = 0.0; z.ub = 0.0; return z; }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const double p = 0.0 * x[j];
+      sa += p;
+      if (RECT && j != 1) s1 += p;
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) sb += 0.0 * u[j];
+    z.xa = sa; z.x1 = s1; z.ub = sb;
+    return z;
+  }
+  // (the 4-state kernels keep the dense rows: four products per row are cheaper than the registers of the second path)
+  static constexpr bool SPARSE = !QUAD && N > 4;
+  __device__ static __forceinline__ bool a_zero(const KArgs& a, int i) { return SPARSE && ((a.azero >> i) & 1ull) != 0ull; }
+  __device__ static __forceinline__ bool b_zero(const KArgs& a, int i) { return SPARSE && ((a.bzero >> i) & 1ull) != 0ull; }
+  __device__ static __forceinline__ double ax_of(const KArgs& a, ctab A, const double* x, int i, const Row& r, const ZeroSums& z) {
+    if (a_zero(a, i)) return RECT ? (0.0 + r.sgn * x[1]) + z.x1 : z.xa;
+    double ax = 0.0;
 #pragma unroll
     for (int j = 0; j < N; ++j) ax += a_ij(A, r, i, j) * x[j];
+    return ax;
+  }
+  __device__ static __forceinline__ double bu_of(const KArgs& a, ctab Bm, const double* u, int i, const ZeroSums& z) {
+    if (b_zero(a, i)) return z.ub;
+    double bu = 0.0;
 #pragma unroll
     for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
+    return bu;
+  }
+  __device__ static __forceinline__ double cval(const KArgs& a, ctab tab, const double* x, const double* u, int i, const Row& r,
+                                                const ZeroSums& z) {
+    ctab A = tab, Bm = tab + a.C * N, Cv = tab + a.C * (N + M);
+    const double ax = ax_of(a, A, x, i, r, z), bu = bu_of(a, Bm, u, i, z);
     if (QUAD) return ((quad_term(a, tab, x, i) + ax) + bu) + c_i(Cv, r, i);
     return ax + bu + c_i(Cv, r, i);
   }
-  __device__ static __forceinline__ double par_cval(const KArgs& a, ctab tab, const double* x, const double* u, int i, const Row& r) {
-    ctab A = tab, Bm = tab + a.C * N, Cv = tab + a.C * (N + M);
-    double ax = 0.0, bu = 0.0;
-#pragma unroll
-    for (int j = 0; j < N; ++j) ax += a_ij(A, r, i, j) * x[j];
-#pragma unroll
-    for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
+  __device__ static __forceinline__ double par_cval(const KArgs& a, ctab tab, const double* x, const double* u, int i, const Row& r,
+                                                    const ZeroSums& z) {
+    ctab Cv = tab + a.C * (N + M);
+    const double ax = ax_of(a, tab, x, i, r, z), bu = bu_of(a, tab + a.C * N, u, i, z);
     double c = ax + bu + c_i(Cv, r, i);
     if (QUAD) c = c + quad_term(a, tab, x, i);
     return c;
@@ -870,9 +906,10 @@ struct NewAlOps {
         ll += l * l;
       }
     }
+    const ZeroSums zs = zero_sums(x, u);
     for_rows(a, lam, ls, [&](int i, const Row& r) {
       const double l = r.l;
-      const double f = l - mu * cval(a, tab, x, u, i, r);
+      const double f = l - mu * cval(a, tab, x, u, i, r, zs);
       double lp = a.eq ? f : fmin(f, 0.0);          // constraints.h:520-528
       pp += lp * lp;
       ll += l * l;
@@ -900,9 +937,10 @@ struct NewAlOps {
         al += pr * pr - l * l;
       }
     }
+    const ZeroSums zs = zero_sums(x, u);
     for_rows(a, lam, ls, [&](int i, const Row& r) {
       const double l = r.l;
-      const double f = l - mu * par_cval(a, tab, x, u, i, r);
+      const double f = l - mu * par_cval(a, tab, x, u, i, r, zs);
       double pr = a.eq ? f : fmin(f, 0.0);
       al += pr * pr - l * l;
     }, box ? NBOX : 0);
@@ -950,10 +988,41 @@ struct NewAlOps {
         }
       }
     }
+    const ZeroSums zs = zero_sums(x, u);
     for_rows(a, lam, ls, [&](int i, const Row& r) {
-      const double fi = r.l - mu * cval(a, tab, x, u, i, r);
+      const double fi = r.l - mu * cval(a, tab, x, u, i, r, zs);
       double lp = a.eq ? fi : fmin(fi, 0.0);        // the equality branch works on the factor itself (constraints.h:673-676)
       double on = a.eq ? 1.0 : ((lp >= 0.0) ? 0.0 : 1.0);
+      const bool az = a_zero(a, i), bz = b_zero(a, i);
+      if (az || bz) {
+        // a zero row (or its overlay  sgn * y) touches at most one gradient and one diagonal Hessian entry; what the
+        // dense code below adds to the others is +-0 at a finite point
+        if (az) {
+          if (RECT) {
+            const double p1 = on * r.sgn;
+            jx[1] += p1 * lp;
+            hx[1][1] += a.eq ? (r.sgn * r.sgn) : ((mu * p1) * r.sgn);
+          }
+        } else {
+          double ca[N], qa[N];
+#pragma unroll
+          for (int j = 0; j < N; ++j) { ca[j] = a_ij(A, r, i, j); qa[j] = on * ca[j]; jx[j] += qa[j] * lp; }
+#pragma unroll
+          for (int p = 0; p < N; ++p)
+#pragma unroll
+            for (int q = 0; q < N; ++q) hx[p][q] += a.eq ? (ca[p] * ca[q]) : ((mu * qa[p]) * ca[q]);
+        }
+        if (!bz) {
+          double qb[M];
+#pragma unroll
+          for (int j = 0; j < M; ++j) { qb[j] = on * Bm[i * M + j]; ju[j] += qb[j] * lp; }
+#pragma unroll
+          for (int p = 0; p < M; ++p)
+#pragma unroll
+            for (int q = 0; q < M; ++q) hu[p][q] += a.eq ? (Bm[i * M + p] * Bm[i * M + q]) : ((mu * qb[p]) * Bm[i * M + q]);
+        }
+        return;
+      }
       double cx[N], pa[N], pb[M];
 #pragma unroll
       for (int j = 0; j < N; ++j) cx[j] = a_ij(A, r, i, j);
@@ -1179,6 +1248,18 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           for (int e = 0; e < N * N; ++e) nz |= (ct[(size_t)t * cw + C * (N + M + 1) + i * N * N + e] != 0.0);
           if (nz) a.quad_rows |= 1ull << i;
         }
+    }
+    // which rows of the shared linear table have no A (no B) entry
+    a.azero = 0ull; a.bzero = 0ull;
+    if (is_new_al(MODE) && !QUAD && a.sparse_rows && a.table_nodes == 1 && a.C <= 64) {
+      ctab ct = as_ctab(a.cons);
+      for (int i = 0; i < C; ++i) {
+        bool za = true, zb = true;
+        for (int j = 0; j < N; ++j) za &= (ct[i * N + j] == 0.0);
+        for (int j = 0; j < M; ++j) zb &= (ct[C * N + i * M + j] == 0.0);
+        if (za) a.azero |= 1ull << i;
+        if (zb) a.bzero |= 1ull << i;
+      }
     }
   }
 

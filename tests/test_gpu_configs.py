@@ -131,8 +131,9 @@ def test_rectangle_obstacle_activation_matches_oracle(name, lanes, tuning):
 @pytest.mark.parametrize("name", ["fast_box", "fast_box_linear", "new_al_box6", "new_al_box6_active", "new_al_lat4", "kin_linear",
                                   "lat_rect", "kin_rect", "fast_equality"])
 def test_single_entry_row_codes_do_not_change_bits(name, tuning):
-    """Box bounds and half-planes are rows with one entry; the kernels evaluate such rows from a per-row code instead
-    of the dense product.  Same bits as the dense rows (the dense_rows tuning override), diverging solves included."""
+    """Box tables are evaluated row by row from the bound's column, and rows of a NEW_AL table without A (B) entries
+    from one sum of zero products per node, instead of the dense products.  Same bits as the dense rows (the dense_rows
+    tuning override), diverging solves included."""
     kw = {}
     if name == "fast_box":
         prob = problems.fast_box(24)
@@ -154,7 +155,7 @@ def test_single_entry_row_codes_do_not_change_bits(name, tuning):
         g = gu.load("fast_equality")
         prob = gu.problem_from_golden(g)
     x0 = np.array(prob[1], dtype=np.float64)
-    x0[0, 1] = np.inf if name in ("fast_box", "new_al_box6") else x0[0, 1]      # a non-finite point takes the dense code
+    x0[0, 1] = np.inf if name in ("fast_box", "new_al_box6", "new_al_lat4", "kin_rect") else x0[0, 1]   # a non-finite point: the dense code / NaN sums
     prob = (prob[0], x0) + tuple(prob[2:])
     tuning(dense_rows=1)
     dense = to_np(batch.solve_batch(*prob, **kw))
