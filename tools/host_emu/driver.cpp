@@ -27,6 +27,8 @@ int main(int argc, char** argv) {
   std::vector<double> x(B * (H + 1) * n), u(B * H * m), nx(x.size()), nu(u.size()), xi(x.size()), ui(u.size()),
       cost(B), viol(B), lam(B * (H + 1) * c), mu(B);
   std::vector<int32_t> st(B * 4);
+  // the emulated group width (threads per group, ALILQR_LANES) must be the kernel's lane-group width
+  alilqr_set_tuning(emu_group_width(), 0, 0);
   int rc = alilqr_solve_batch_ex(&p, x0.data(), goals.data(), Q.data(), R.data(), cons.data(), &ex, x.data(), u.data(), nx.data(), nu.data(),
                               xi.data(), ui.data(), cost.data(), viol.data(), lam.data(), mu.data(), st.data(), nullptr);
   printf("rc %d %s\n", rc, alilqr_last_error());

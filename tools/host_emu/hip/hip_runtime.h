@@ -14,6 +14,7 @@
 #define __host__
 #define __global__
 #define __forceinline__ inline
+#define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define __shared__
 // dynamic LDS of the emulated wave (block-scope `extern __shared__` declarations inside namespace alilqr bind here)
@@ -47,6 +48,15 @@ template <class T> inline T __shfl(T v, int src, int width) {
   T o; std::memcpy(&o, &r, sizeof(T));
   return o;
 }
+// wave-wide form (source = a lane of the wave): only the LEGACY line search uses it, to read the state of another group
+// of the wave; groups run one after the other here, so only sources inside the own group can be served
+template <class T> inline T __shfl(T v, int src) {
+  emu_group* g = emu_grp;
+  const int G = g ? g->G : 1, base = (threadIdx.x & 63) & ~(G - 1);
+  if (src < base || src >= base + G) { std::fprintf(stderr, "host emulation: cross-group __shfl (LEGACY line search) is not emulated\n"); std::abort(); }
+  return __shfl(v, src - base, G);
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 // ballot over the group only, placed at the group's bit positions inside the wave
 inline unsigned long long __ballot(bool p) {
   emu_group* g = emu_grp;
@@ -85,6 +95,17 @@ inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy(d, s, n); return hipSuccess; }
 constexpr int hipMemcpyDeviceToHost = 2;
+typedef void* hipEvent_t;
+constexpr unsigned hipEventDisableTiming = 2;
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+#define __align__(n) alignas(n)
+#define HIP_SYMBOL(x) (&(x))
+template <class T> inline hipError_t hipGetSymbolAddress(void** p, T* sym) { *p = (void*)sym; return hipSuccess; }
 
 // every block, every group, one after the other; the lanes of a group as threads
 inline int emu_group_width() { const char* e = std::getenv("ALILQR_LANES"); int g = e ? std::atoi(e) : 1; return g < 1 ? 1 : g; }
