@@ -765,7 +765,9 @@ struct NewAlOps {
 #ifdef ALILQR_EXP_ROWS_AHEAD
   static constexpr int ROWS_AHEAD = ALILQR_EXP_ROWS_AHEAD;
 #else
-  static constexpr int ROWS_AHEAD = 1;   // measured: 4 or 8 rows ahead change nothing (the row loop is bound by its arithmetic) and cost registers
+  // measured: more rows ahead change nothing or cost registers, except with the rectangle overlay of the 6-state model
+  // (three loads per row): 4 rows ahead are 7 % there, 8 spill
+  static constexpr int ROWS_AHEAD = (RECT && N > 4) ? 4 : 1;
 #endif
   static constexpr int NBOX = 2 * (N + M);
   // does this node evaluate the leading rows of its table as box rows?  (linear tables without rectangle overlay;
