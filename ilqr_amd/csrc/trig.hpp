@@ -23,25 +23,43 @@ __device__ __noinline__ SinCos sincos_far(double x) {
 __device__ __noinline__ double tan_far(double x) { return tan(x); }
 __device__ __noinline__ double fmod_far(double x, double y) { return fmod(x, y); }
 
+// One Horner step  a * b + c  with a coefficient c that lives on.  Written as the three-address instruction: left to
+// the compiler a step becomes a copy of the coefficient plus the two-address v_fmac_f64 that overwrites the copy -
+// one move per coefficient, 45 per roll-out step of the lateral model.  Same operation, same bits.
+// (Measured: it pays in the 4-state LEGACY roll-out, +2 %, and costs registers elsewhere - the 6-state and the
+// NEW_AL kernels keep the compiler's form: THREE = false.)
+template <bool THREE>
+__device__ __forceinline__ double horner(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (THREE) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+  }
+#endif
+  return fma(a, b, c);
+}
+
+template <bool THREE = false>
 __device__ __forceinline__ void sincos_kernels(double r, double* s, double* c) {
   const double z = r * r;
   // sin
   const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-  double ps = fma(z, S6, S5);
-  ps = fma(z, ps, S4);
-  ps = fma(z, ps, S3);
-  ps = fma(z, ps, S2);
+  double ps = horner<THREE>(z, S6, S5);
+  ps = horner<THREE>(z, ps, S4);
+  ps = horner<THREE>(z, ps, S3);
+  ps = horner<THREE>(z, ps, S2);
   const double v = z * r;
-  *s = fma(v, fma(z, ps, S1), r);
+  *s = fma(v, horner<THREE>(z, ps, S1), r);
   // cos
   const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  double pc = fma(z, C6, C5);
-  pc = fma(z, pc, C4);
-  pc = fma(z, pc, C3);
-  pc = fma(z, pc, C2);
-  pc = fma(z, pc, C1);
+  double pc = horner<THREE>(z, C6, C5);
+  pc = horner<THREE>(z, pc, C4);
+  pc = horner<THREE>(z, pc, C3);
+  pc = horner<THREE>(z, pc, C2);
+  pc = horner<THREE>(z, pc, C1);
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
   *c = w + (((1.0 - w) - hz) + z * (z * pc));
@@ -71,7 +89,7 @@ __device__ __forceinline__ void sincos_pi(double x, double* s, double* c) {
   double r = fma(-q, 1.57079632679489655800e+00, x);
   r = fma(-q, 6.12323399573676603587e-17, r);
   double sr, cr;
-  sincos_kernels(r, &sr, &cr);
+  sincos_kernels<true>(r, &sr, &cr);
   const int n = (int)q;
   const double ss = (n & 1) ? cr : sr;
   const double cc = (n & 1) ? sr : cr;
@@ -80,6 +98,7 @@ __device__ __forceinline__ void sincos_pi(double x, double* s, double* c) {
 }
 
 // tan on |x| < 0.67434 by the odd minimax polynomial of the fdlibm tangent kernel (< 1 ulp)
+template <bool THREE = false>
 __device__ __forceinline__ double tan_poly(double x) {
   const double T0 = 3.33333333333334091986e-01, T1 = 1.33333333333201242699e-01, T2 = 5.39682539762260521377e-02,
                T3 = 2.18694882948595424599e-02, T4 = 8.86323982359930005737e-03, T5 = 3.59207910759131235356e-03,
@@ -88,16 +107,16 @@ __device__ __forceinline__ double tan_poly(double x) {
                T12 = 2.59073051863633712884e-05;
   const double z = x * x;
   const double w = z * z;
-  double r = fma(w, T11, T9);
-  r = fma(w, r, T7);
-  r = fma(w, r, T5);
-  r = fma(w, r, T3);
-  r = fma(w, r, T1);
-  double v = fma(w, T12, T10);
-  v = fma(w, v, T8);
-  v = fma(w, v, T6);
-  v = fma(w, v, T4);
-  v = fma(w, v, T2);
+  double r = horner<THREE>(w, T11, T9);
+  r = horner<THREE>(w, r, T7);
+  r = horner<THREE>(w, r, T5);
+  r = horner<THREE>(w, r, T3);
+  r = horner<THREE>(w, r, T1);
+  double v = horner<THREE>(w, T12, T10);
+  v = horner<THREE>(w, v, T8);
+  v = horner<THREE>(w, v, T6);
+  v = horner<THREE>(w, v, T4);
+  v = horner<THREE>(w, v, T2);
   v = z * v;
   const double s3 = z * x;
   r = z * (s3 * (r + v));
@@ -107,7 +126,7 @@ __device__ __forceinline__ double tan_poly(double x) {
 
 // tan for wrapped angles (|x| <= 4 or NaN): polynomial on small angles, sin/cos beyond
 __device__ __forceinline__ double tan_pi(double x) {
-  if (__builtin_expect(fabs(x) < 0.67434, 1)) return tan_poly(x);
+  if (__builtin_expect(fabs(x) < 0.67434, 1)) return tan_poly<true>(x);
   double s, c;
   sincos_pi(x, &s, &c);
   return s / c;
