@@ -7,7 +7,7 @@ with seed = rank) per GPU, weak scaling.  Inputs are resident in HBM before the 
 exchange data, so the ranks shard the batch with no collective inside the solve; one gather of the final cost
 vectors over RCCL at the end of the K steps is the only exchange.
 
-Consecutive steps are independent batches.  They are enqueued on --pipeline (default 6) HIP streams in turn, each
+Consecutive steps are independent batches.  They are enqueued on --pipeline (default 12, at most 16) HIP streams in turn, each
 with its own output buffers and its own scratch inside the library, so the next batches fill the SIMDs that the
 tail of a batch leaves idle (a batch ends when its longest solve ends).  The process asks the HIP runtime for 16
 hardware queues (--hw-queues): with the default 4, streams share queues and their kernels run one after the other.
@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = the library's choice)")
-    ap.add_argument("--pipeline", type=int, default=6, help="batches in flight (HIP streams used in turn)")
+    ap.add_argument("--pipeline", type=int, default=12, help="batches in flight (HIP streams used in turn)")
     ap.add_argument("--hw-queues", type=int, default=16,
                     help="GPU_MAX_HW_QUEUES for this process (HIP's default of 4 makes streams share a hardware "
                          "queue, and kernels on one queue run one after the other); 0 leaves the environment's value")
@@ -185,7 +185,7 @@ def main():
     if B < 1:
         raise SystemExit("this rank has no problems: use a larger --batch")
 
-    depth = max(1, min(8, args.pipeline))
+    depth = max(1, min(16, args.pipeline))
     solvers = [batch.BatchSolver(*prob, extras=False, device=dev, **kw) for _ in range(depth)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
@@ -298,7 +298,10 @@ def main():
                          # HBM bytes per launch from the PMC passes of this build (null when none is committed for it)
                          "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
                          "counters": pmc,
-                         "kernel": "alilqr::solve_kernel", "kernel_ms": kernel_ms,
+                         # kernel_ms is a launch as it experienced the machine: `launches_in_flight` launches share the GPU, so
+                         # a launch lasts about that many times its share; achieved_job / frac_job are the algorithmic
+                         # flops of all K launches over the wall time of the timed region
+                         "kernel": "alilqr::solve_kernel", "kernel_ms": kernel_ms, "launches_in_flight": depth,
                          "achieved_job": tf_job, "frac_job": tf_job / FP64_VALU_PEAK_TFLOPS,
                          "algorithmic_flops_per_launch": flops,
                          "algorithmic_hbm_bytes_per_launch": algorithmic_bytes(desc),

@@ -100,7 +100,7 @@ if out:
     import bench
     summary["kernel_source_id"] = bench.kernel_source_id()
     summary["config"] = "2"
-    summary["command"] = "python3 bench.py --steps 1 --warmup 0 --no-cpu (8 launches of the headline batch: 6 priming, 1 timed, 1 alone; per-launch averages)"
+    summary["command"] = "python3 bench.py --steps 1 --warmup 0 --no-cpu (14 launches of the headline batch: 12 priming, 1 timed, 1 alone; per-launch averages)"
     open(os.path.join(P, tag + "_pmc.txt"), "w").write("\n".join(out) + "\n")
     json.dump(summary, open(os.path.join(P, tag + "_pmc.json"), "w"), indent=1)
 print("\n".join(lines + out))
