@@ -1822,10 +1822,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         RecRegs RA, RB;
         load_rec(tg, 0, RA, closed);
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-          x[i] = tg.cur[i];
-          if (valid && sslot >= 0) tout[i] = x[i];
-        }
+        for (int i = 0; i < N; ++i) x[i] = tg.cur[i];
         double uown[M];
 #pragma unroll
         for (int r = 0; r < M; ++r) uown[r] = (LEGACY && kind == 1 && valid && !(LDSUC && fly2)) ? ucol[(size_t)r * ucs] : 0.0;
@@ -1858,25 +1855,33 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           }
           if (valid) {
             double xn[N];
+            // The node's (x_t, u_t) is stored between its cost and its dynamics: the stores then complete under the
+            // dynamics' arithmetic instead of ahead of the next node's loads (loads and stores share one in-order
+            // counter, so a wait for a load also waits for every store issued before it).
+            auto keep = [&]() {
+              if (sslot >= 0) {
+#pragma unroll
+                for (int r = 0; r < M; ++r) tout[XS + t * M + r] = u[r];
+#pragma unroll
+                for (int i = 0; i < N; ++i) tout[t * N + i] = x[i];
+              }
+            };
             if constexpr (NEWAL) {
               const double* lp = rec(t) + (size_t)RL::rl * ES;
               if (kind == 2) {
                 J += OPS::par_cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, lp, ES, mu);
+                keep();
                 MD::par_step(mc, x, u, xn);
               } else {
                 J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, lp, ES, mu);
+                keep();
                 MD::template step<false>(mc, x, u, xn);
               }
             } else {
               if (LEGACY) J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, R.lam, 1, mu);
               else J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, rec(t) + (size_t)RL::rl * ES, ES, mu);
+              keep();
               MD::template step<true>(mc, x, u, xn);
-            }
-            if (sslot >= 0) {
-#pragma unroll
-              for (int r = 0; r < M; ++r) tout[XS + t * M + r] = u[r];
-#pragma unroll
-              for (int i = 0; i < N; ++i) tout[(t + 1) * N + i] = xn[i];
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) x[i] = xn[i];
@@ -1899,6 +1904,10 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           }
         }
         if (valid) {
+          if (sslot >= 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) tout[H * N + i] = x[i];
+          }
           double zu[M];
 #pragma unroll
           for (int r = 0; r < M; ++r) zu[r] = 0.0;
