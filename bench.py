@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = the library's choice)")
+    ap.add_argument("--max-waves", type=int, default=0,
+                    help="resident waves per launch (0 = the library's choice); with fewer waves than problem pairs a lane "
+                         "group pulls its next problem when it finishes one")
     ap.add_argument("--pipeline", type=int, default=12, help="batches in flight (HIP streams used in turn)")
     ap.add_argument("--hw-queues", type=int, default=16,
                     help="GPU_MAX_HW_QUEUES for this process (HIP's default of 4 makes streams share a hardware "
@@ -162,8 +165,8 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    if args.lanes:
-        capi.set_tuning(lanes=args.lanes)
+    if args.lanes or args.max_waves:
+        capi.set_tuning(lanes=args.lanes, max_waves=args.max_waves)
     cfg = CONFIGS[args.config]
     scaling = args.scaling or cfg["scaling"]
     total = args.batch or cfg["batch"]
