@@ -255,6 +255,17 @@ def main():
         e0.record(streams[0]); solvers[0].run(streams[0].cuda_stream); e1.record(streams[0])
     torch.cuda.synchronize(dev)
     lone_ms = e0.elapsed_time(e1)
+    # and a launch that leaves every wave a SIMD to itself (1024 problems = 512 waves on 1024 SIMDs): the latency of
+    # one iLQR iteration when nothing else competes for the wave's SIMD
+    light_B = min(B, 1024)
+    lprob, lkw = make_workload(args.config, light_B, rank)
+    light = batch.BatchSolver(*lprob, extras=False, device=dev, **lkw)
+    with torch.cuda.stream(streams[0]):
+        light.run(streams[0].cuda_stream)                      # set-up: scratch of this size
+        e0.record(streams[0]); lout = light.run(streams[0].cuda_stream); e1.record(streams[0])
+    torch.cuda.synchronize(dev)
+    light_ms = e0.elapsed_time(e1)
+    light_iters = int(lout["status"][:, 0].max().item())
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     status = out["status"].cpu().numpy()
@@ -290,6 +301,9 @@ def main():
                        # latency of one iLQR iteration (linearise, backward sweep, line search) of one problem with the
                        # whole batch resident: a lone launch lasts as long as its longest solve
                        "per_iter_latency_us": lone_ms * 1e3 / max(1, int(status[:, 0].max())),
+                       # the same with 1024 problems resident (one wave per SIMD at most)
+                       "light_load": {"batch": light_B, "launch_ms": light_ms,
+                                      "per_iter_latency_us": light_ms * 1e3 / max(1, light_iters)},
                        "mean_inner_iters": float(status[:, 0].mean()), "mean_rollouts": float(status[:, 3].mean()),
                        # "converged" = reached the reference generation's own stopping state: violation below its
                        # tolerance, or its outer-iteration cap (the reference stops there too); both shares are given
