@@ -88,30 +88,38 @@ def kernel_source_id():
 
 
 def measured_counters(config):
-    """HBM traffic per launch and VALU counters from the committed rocprofv3 --pmc passes of THIS build, or None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
-    try:
-        with open(path) as fh:
-            c = json.load(fh)
-    except (OSError, ValueError):
-        return None
-    if c.get("kernel_source_id") != kernel_source_id() or str(c.get("config")) != config:
-        return None
-    c["source"] = "profiles/r02_pmc.json"
-    return c
+    """HBM traffic per launch and VALU counters from the committed rocprofv3 --pmc passes of THIS build (the summary's
+    kernel_source_id must be the tree's), or None.  profiles/r03_pmc_<config>.json, written by tools/profile_round.sh."""
+    for name in (f"r03_pmc_{config}.json", "r02_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                c = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if c.get("kernel_source_id") == kernel_source_id() and str(c.get("config")) == config:
+            c["source"] = "profiles/" + name
+            return c
+    return None
 
 
-def cpu_baseline(sample):
-    """The CPU oracle (a restatement of the reference, 'port') on a bounded sample of the default workload."""
+def cpu_baseline(config, sample, seed=0):
+    """The CPU oracle (a restatement of the reference, 'port') on a bounded sample of the configuration's workload:
+    its first `sample` problems (whole scenarios for the multi-start configuration), OpenMP over problems."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     threads = max(1, min(16, os.cpu_count() or 1, oracle_lib.lib().oracle_max_threads()))
-    desc, x0, goals, Q, R, cons = problems.lat_legacy(sample, 50, seed=0)
+    if config == "5":
+        sample = max(STARTS, sample // STARTS * STARTS)
+    prob, kw = make_workload(config, sample, seed)
     t0 = time.perf_counter()
-    oracle_lib.solve_batch(desc, x0, goals, Q, R, cons, threads=threads, extras=False)
+    oracle_lib.solve_batch(*prob, threads=threads, extras=False, **kw)
     dt = time.perf_counter() - t0
     return dict(value=sample / dt, unit="solves/s", cores=threads, kind="port",
-                sample=f"the first {sample} problems of the 4096-problem batch of rank 0, OpenMP over problems, {dt:.2f} s wall")
+                sample=f"the first {sample} problems of rank 0's batch of configuration {config}, OpenMP over problems, {dt:.2f} s wall")
+
+
+# problems of the CPU-baseline sample per configuration: about 3 - 20 s of work on 16 host cores
+CPU_SAMPLE = {"2": 4096, "3": 2048, "4a": 1024, "4b": 2048, "5": 4096}
 
 
 def main():
@@ -122,7 +130,7 @@ def main():
     ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU (weak) or in total (strong); 0 = the configuration's")
-    ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="problems of the CPU-baseline sample (0 = the configuration's)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per problem (0 = the library's choice)")
     ap.add_argument("--max-waves", type=int, default=0,
@@ -326,7 +334,7 @@ def main():
                          "hbm_peak_GBs": HBM_PEAK_GBS, "kernel_source_id": kernel_source_id()},
         }
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+            line["cpu_baseline"] = cpu_baseline(args.config, min(B, args.cpu_sample or CPU_SAMPLE[args.config]))
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -36,7 +36,8 @@ def _require_gpu(device):
 
 
 def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=True, u_offset=None,
-                left_obs=None, right_obs=None, first_row=0, trace=0, mu_solver=None, first_rows=None, overlay=False):
+                left_obs=None, right_obs=None, first_row=0, trace=0, mu_solver=None, first_rows=None, overlay=False,
+                stop_after=None):
     """Solve ``desc.batch`` problems on the GPU.
 
     Inputs may be numpy arrays or torch tensors (moved to ``device`` as fp64):
@@ -50,6 +51,8 @@ def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=
     final row index per node).
     ``trace`` > 0 also returns iter_cost / trials [B,trace]: the cost after every inner iteration and the roll-outs
     of its line search (what the reference prints while it runs); entries beyond status[:,0] are NaN / 0.
+    ``stop_after`` (diagnostic; int or [B]): problem b ends right after its stop_after[b]-th inner iteration, status
+    flag FLAG_STOPPED; node_x / node_u / cost are then the iterate of that iteration.
     Returns a dict of device tensors: x [B,H+1,n], u [B,H,m], cost [B], status [B,4] and, with
     ``extras``, node_x, node_u, x_init, u_init, viol, lam, mu.
     """
@@ -88,14 +91,21 @@ def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=
             keep.append(ms)
             ex.mu_solver_in = ms.data_ptr()
     if first_rows is not None:
-        fr = torch.as_tensor(np.ascontiguousarray(first_rows, dtype=np.int32), device=dev)
-        if fr.numel() != H + 1:
+        fr_h = np.ascontiguousarray(first_rows, dtype=np.int32)
+        if fr_h.size != H + 1:
             raise ValueError("first_rows must hold H+1 values")
+        if fr_h.size and (fr_h.min() < 0 or fr_h.max() >= c):
+            raise ValueError("every first_rows entry must be a row of the table (0 <= row < c)")
+        fr = torch.as_tensor(fr_h, device=dev)
         keep.append(fr)
         ex.first_rows = fr.data_ptr()
     if overlay:
         out["overlay"] = torch.zeros((B, H + 1, 2 * c + 1), **f64)
         ex.overlay_out = out["overlay"].data_ptr()
+    if stop_after is not None:
+        sa = torch.as_tensor(np.ascontiguousarray(np.broadcast_to(np.asarray(stop_after, dtype=np.int32), (B,))), device=dev)
+        keep.append(sa)
+        ex.stop_after = sa.data_ptr()
     if trace > 0:
         out.update(iter_cost=torch.full((B, int(trace)), float("nan"), **f64),
                    trials=torch.zeros((B, int(trace)), dtype=torch.int32, device=dev))

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 STATUS_WORDS = 4
 
 MODELS = {"lat": 0, "kin": 1, "dyn": 2, "dyn_mid": 3, "lat_k": 4, "new_bicycle": 5, "lon": 6, "lat_interior": 7}
@@ -19,6 +19,7 @@ DV_GATE = 0.20000000298023224   # the float literal 0.2F of new_al_ilqr.h:1039, 
 FLAG_VIOL_OK = 1
 FLAG_OUTER_CAP = 2
 FLAG_NONFINITE = 4
+FLAG_STOPPED = 8
 
 E_ARG, E_HIP, E_NOMEM, E_NODEVICE = -1, -2, -3, -4
 
@@ -47,7 +48,7 @@ class Extras(C.Structure):
                 ("n_left", C.c_int32), ("n_right", C.c_int32), ("first_row", C.c_int32), ("reserved", C.c_int32),
                 ("trace_cost", C.c_void_p), ("trace_trials", C.c_void_p), ("trace_cap", C.c_int32), ("reserved2", C.c_int32),
                 ("mu_solver_in", C.c_void_p), ("mu_solver_out", C.c_void_p), ("first_rows", C.c_void_p),
-                ("overlay_out", C.c_void_p)]
+                ("overlay_out", C.c_void_p), ("stop_after", C.c_void_p)]
 
 
 def pack_rectangles(rects):

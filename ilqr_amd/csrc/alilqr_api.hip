@@ -571,6 +571,7 @@ static int32_t solve_impl(const alilqr_problem* p,
     }
     base = (char*)ss->ptr;
     counter_next = &ss->counter_next;
+    g_last_ws[dev] = ss->ptr;
   } else {
     rc = take_slot(dev, st, pl.total, &slot);
     if (rc != ALILQR_OK) return rc;
@@ -602,6 +603,7 @@ static int32_t solve_impl(const alilqr_problem* p,
     if ((ex->first_rows || ex->overlay_out) && !rect) { set_err("first_rows / overlay_out need rectangle obstacles"); return ALILQR_E_ARG; }
     ka.mu_s_in = ex->mu_solver_in; ka.mu_s_out = ex->mu_solver_out; ka.first_rows = ex->first_rows; ka.overlay_out = ex->overlay_out;
   }
+  if (ex) ka.stop_after = ex->stop_after;
   if (rect) { ka.left_obs = ex->left_obs; ka.right_obs = ex->right_obs; ka.n_left = n_left; ka.n_right = n_right; ka.first_row = ex->first_row; }
   ka.x_out = x_out; ka.u_out = u_out; ka.node_x = node_x; ka.node_u = node_u;
   ka.x_init = x_init; ka.u_init = u_init; ka.cost = cost; ka.viol = viol; ka.lam = lam; ka.mu = mu;
@@ -635,8 +637,15 @@ static int32_t solve_impl(const alilqr_problem* p,
   if (lr == alilqr::LAUNCH_OK) {
     *counter_next += (unsigned)p->batch + (unsigned)pl.NG;
     if (slot) {
-      HIP_TRY(hipEventRecord(slot->done, st));
+      // the slot is in use from here on, whatever happens to the event: a later solve must wait for this kernel
       slot->used = true; slot->stream = st; slot->tick = ++g_tick;
+      const hipError_t e = hipEventRecord(slot->done, st);
+      if (e != hipSuccess) {
+        // without the event nothing orders later users of the slot behind this kernel: let it finish now
+        (void)hipStreamSynchronize(st);
+        set_err("%s: %s", "hipEventRecord(slot->done)", hipGetErrorString(e));
+        return ALILQR_E_HIP;
+      }
     }
     return ALILQR_OK;
   }

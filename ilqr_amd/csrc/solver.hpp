@@ -141,6 +141,7 @@ struct KArgs {
   double* mu_s_out;           // NEW_AL, optional [B]: the solver-level penalty after this solve
   const int32_t* first_rows;  // RECT, optional [H+1]: per-node initial row index (null: first_row)
   double* overlay_out;        // RECT, optional [B][H+1][2C+1]: row signs | replacement constants | row index per node
+  const int32_t* stop_after;  // optional [B]: inner iteration after which a problem ends (diagnostic), or null
   double *x_out, *u_out, *node_x, *node_u, *x_init, *u_init, *cost, *viol, *lam, *mu;
   int32_t* status;
   double *trj, *blk, *ucum;
@@ -1291,6 +1292,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   bool keep_old = false, gate_skip = false, have = false;
   int win_trial = -1, win_lane = -1, r0 = 0, replay_kind = 0;
   int nt0 = 0;                // roll-out count when the running line search started (trace output)
+  int stop_k = 0;             // the problem ends after this inner iteration (alilqr_extras::stop_after), 0: never
   bool xo_pend = false;       // the (x, u) pair to return is a trajectory in the slots, not yet copied to x_out / u_out
   int xo_par = 0, xo_slot = 0;
   // LEGACY: bit t set = some multiplier of node t is not zero (nodes 0 .. 127; longer horizons load them always).
@@ -1387,7 +1389,10 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           for (int i = 0; i < C; ++i) r[(size_t)(RL::rl + i) * ES] = 0.0;
           if (RECT) {
             for (int i = 0; i < 2 * C; ++i) r[(size_t)(RL::rl + C + i) * ES] = 0.0;
-            r[(size_t)(RL::rl + 3 * C) * ES] = (double)(a.first_rows ? a.first_rows[t] : a.first_row);
+            // the caller's per-node start rows are device data the host cannot check: keep them inside the table
+            int fr = a.first_rows ? a.first_rows[t] : a.first_row;
+            fr = fr < 0 ? 0 : (fr >= C ? C - 1 : fr);
+            r[(size_t)(RL::rl + 3 * C) * ES] = (double)fr;
           }
         }
         // ---- linearised-LQR initial guess (ilqr.py:11-50): every lane of the group
@@ -1510,6 +1515,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         }
         mu = 1.0;
         mu_s = (NEWAL && a.mu_s_in) ? a.mu_s_in[p] : 1.0;
+        stop_k = a.stop_after ? a.stop_after[p] : 0;
         xo_pend = false;
         cur_slot = 0; cur_par = 0;
         outer = 0; inner = 0; n_inner = 0; n_trials = 0;
@@ -2179,7 +2185,8 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
       }
       bool finished = false;
       unsigned flags = 0;
-      if (brk || inner >= a.prm.max_inner) {
+      const bool stop_now = stop_k > 0 && n_inner >= stop_k;
+      if (brk || inner >= a.prm.max_inner || stop_now) {
         if (!NEWAL && xo_pend) {
           // The pair to return is the trajectory of the last iteration that did not end the inner loop.  It sits in
           // the parity this iteration's candidates were NOT written to (or is the one just accepted), so it is
@@ -2188,6 +2195,10 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           for (int e = gl; e < US; e += G) a.u_out[(size_t)p * US + e] = *trj_at(xo_par, XS + e, xo_slot);
           xo_pend = false;
         }
+      }
+      if (stop_now) {
+        finished = true; flags = ALILQR_FLAG_STOPPED;
+      } else if (brk || inner >= a.prm.max_inner) {
         // constraint violation of the node trajectory, nodes in parallel, combined in node order
         double vtot = OPS::violation_init();
         for (int t0 = 0; t0 <= H; t0 += G) {

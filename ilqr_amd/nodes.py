@@ -20,11 +20,13 @@ from . import capi
 # constraints (cilqr/constraints.py, linear_constraints.py, box_constrains.py)
 # ---------------------------------------------------------------------------
 class Constraints(ABC):
-    """Inequality (or equality) constraints c(x,u) <= 0 with multipliers ``lambda_`` (<= 0) and penalty ``mu``.
+    """Inequality (or equality) constraints c(x,u) <= 0 with multipliers ``lambda_`` (<= 0) and penalty ``mu``
+    (cilqr/constraints.py:4-119).
 
-    The scalar helpers below (projection, multiplier update, violation, AL value / gradient / Hessian of ONE
-    point) are small host-side utilities kept so that scripts written against the reference keep working;
-    the batched solve never calls them — it evaluates the same formulas on the GPU from the table (A, B, C).
+    The augmented-Lagrangian calls (cost / gradient / Hessian of one point, multiplier update, violation) are evaluated
+    by the HIP node kernels, which take constraint TABLES: they exist for ``LinearConstraints`` / ``BoxConstraint``
+    below.  A subclass with a Python ``constrains()`` of its own cannot be evaluated on the GPU; for it these calls
+    raise, as the batched solve does.
     """
 
     def __init__(self, constraint_dim, is_equality=False):
@@ -74,52 +76,15 @@ class Constraints(ABC):
     def projection_hessian(self, x, b):
         return np.zeros((x.size, x.size))
 
-    def augmented_lagrangian_cost(self, x, u):
-        self.c = self.constrains(x, u)
-        f = self._lambda - self._mu * self.c
-        if not self.is_equality:
-            f = self.lambda_proj = self.projection(f)
-        return 0.5 / self._mu * (f @ f - self._lambda @ self._lambda)
+    def _no_table(self, *a, **k):
+        raise NotImplementedError("the augmented-Lagrangian terms are evaluated on the GPU from a constraint table: "
+                                  "use LinearConstraints / BoxConstraint")
 
-    def augmented_lagrangian_jacobian(self, x, u):
-        self.c = self.constrains(x, u)
-        self.cx, self.cu = self.constrains_jacobian(x, u)
-        f = self._lambda - self._mu * self.c
-        if self.is_equality:
-            return (-self.cx.T @ f).astype(np.float64), (-self.cu.T @ f).astype(np.float64)
-        self.lambda_proj = self.projection(f)
-        self.proj_jac = self.projection_jacobian(f)
-        return (-(self.proj_jac @ self.cx).T @ self.lambda_proj).astype(np.float64), \
-            (-(self.proj_jac @ self.cu).T @ self.lambda_proj).astype(np.float64)
-
-    def augmented_lagrangian_hessian(self, x, u, full_newton=False):
-        self.c = self.constrains(x, u)
-        self.hx, self.hu, self.hxu = self.constrains_hessian(x, u)
-        self.cx, self.cu = self.constrains_jacobian(x, u)
-        f = self._lambda - self._mu * self.c
-        if self.is_equality:
-            px, pu, w = self.cx, self.cu, f
-        else:
-            self.lambda_proj = w = self.projection(f)
-            self.proj_jac = self.projection_jacobian(f)
-            px, pu = self.proj_jac @ self.cx, self.proj_jac @ self.cu
-        dxdx = self._mu * (px.T @ px) - np.einsum('j,jkl->kl', w, self.hx)
-        dxdu = self._mu * (px.T @ pu) - np.einsum('j,jkl->kl', w, self.hxu)
-        dudu = self._mu * (pu.T @ pu) - np.einsum('j,jkl->kl', w, self.hu)
-        return dxdx.astype(np.float64), dudu.astype(np.float64), dxdu.astype(np.float64)
-
-    def update_lambda(self):
-        if self.is_equality:
-            self._lambda = self._lambda - self._mu * self.c
-        else:
-            self._lambda = self.projection(self._lambda - self._mu * self.c)
+    augmented_lagrangian_cost = augmented_lagrangian_jacobian = augmented_lagrangian_hessian = _no_table
+    update_lambda = max_violation = _no_table
 
     def update_mu(self, new_mu):
         self._mu = new_mu
-
-    def max_violation(self, x, u):
-        self.c = self.constrains(x, u)
-        return np.linalg.norm(self.c - self.projection(self.c), ord=np.inf)
 
 
 class LinearConstraints(Constraints):
@@ -144,6 +109,65 @@ class LinearConstraints(Constraints):
         self.hu = np.zeros((self.constraint_dim, u.size, u.size))
         self.hxu = np.zeros((self.constraint_dim, x.size, u.size))
         return self.hx, self.hu, self.hxu
+
+    # -- augmented-Lagrangian calls of cilqr/constraints.py:59-119 on the GPU ------------------------------------
+    # The node kernel of the FAST generation evaluates  l = e'Qe + u'Ru + AL  and its derivatives for a 6-state /
+    # 2-control table (the only shape FastILQR has a node for, fast_bicycle_node.py:7-16); with Q = 0, R = 0 what
+    # it returns IS the AL value, gradient and Hessian blocks.
+    def _gpu_point(self, x, u):
+        from . import batch
+        x = np.asarray(x, dtype=np.float64).reshape(-1)
+        u = np.asarray(u, dtype=np.float64).reshape(-1)
+        c = self.constraint_dim
+        if self.A.shape != (c, 6) or self.B.shape != (c, 2) or x.size != 6 or u.size != 2:
+            raise NotImplementedError("the GPU node kernels of this generation take 6-state / 2-control tables")
+        desc = capi.make_problem("dyn_mid", "fast", 1, 1, 1.0, 0.1, c=c,
+                                 cons_kind=capi.CONS_EQUALITY if self.is_equality else capi.CONS_LINEAR)
+        xs = np.zeros((1, 2, 6)); xs[0, 0] = x
+        us = np.zeros((1, 2, 2)); us[0, 0] = u
+        ls = np.zeros((1, 2, c)); ls[0, 0] = np.asarray(self._lambda, dtype=np.float64)
+        args = (desc, xs, us, ls, np.array([float(self._mu)]), np.zeros((2, 6)), np.zeros((6, 6)), np.zeros((2, 2)),
+                capi.pack_linear(self.A, self.B, self.C))
+        return batch, args
+
+    def augmented_lagrangian_cost(self, x, u):
+        batch, args = self._gpu_point(x, u)
+        return float(batch.linearize_batch(*args)["l"][0, 0])
+
+    def augmented_lagrangian_jacobian(self, x, u):
+        batch, args = self._gpu_point(x, u)
+        out = batch.linearize_batch(*args)
+        return out["lx"][0, 0].cpu().numpy(), out["lu"][0, 0].cpu().numpy()
+
+    def augmented_lagrangian_hessian(self, x, u, full_newton=False):
+        """(dxdx, dudu, dxdu).  The mixed block is used by no solver generation (fast_bicycle_node.py:209 drops it)
+        and the node kernel does not form it: it is assembled on the device from the kernel's constraint values
+        and Jacobians."""
+        batch, args = self._gpu_point(x, u)
+        out = batch.linearize_batch(*args)
+        desc, xs, us, ls, mu = args[0], args[1], args[2], args[3], float(self._mu)
+        cb = batch.constraints_batch(desc, xs, us, args[8])
+        f = out["lx"].new_tensor(ls[0, 0]) - mu * cb["cval"][0, 0]
+        on = (f <= 0).to(f.dtype) if not self.is_equality else f.new_ones(f.shape)
+        dxdu = mu * (on[:, None] * cb["jac_x"][0, 0]).T @ (on[:, None] * cb["jac_u"][0, 0])
+        return out["lxx"][0, 0].cpu().numpy(), out["luu"][0, 0].cpu().numpy(), dxdu.cpu().numpy()
+
+    def _aux(self, x, u):
+        batch, args = self._gpu_point(x, u)
+        return batch.node_aux_batch(*args)
+
+    def max_violation(self, x, u):
+        out = self._aux(x, u)
+        self.c = out["cval"][0, 0].cpu().numpy()
+        self._last_point = (np.array(x, dtype=np.float64), np.array(u, dtype=np.float64))
+        return float(out["viol"][0, 0])
+
+    def update_lambda(self):
+        """lambda <- projection(lambda - mu c) at the point of the preceding max_violation call (constraints.py:106-110
+        uses the constraint values that call cached)."""
+        if getattr(self, "_last_point", None) is None:
+            raise RuntimeError("update_lambda follows a max_violation call (it uses the constraint values cached there)")
+        self._lambda = self._aux(*self._last_point)["lam_new"][0, 0].cpu().numpy()
 
 
 class BoxConstraint(LinearConstraints):

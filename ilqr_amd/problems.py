@@ -55,12 +55,14 @@ def lat_legacy(B, H=50, seed=0, x0=None):
     return desc, np.ascontiguousarray(x0, dtype=np.float64), s_curve_goals(10.0, 0.1, H, False), Q, R, cons
 
 
-def full_legacy(model, B, H, seed, x0=None):
-    """ILQR + FullBicycle{Kinematic,Dynamic}Node with the converging (soft) weights."""
+def full_legacy(model, B, H, seed, x0=None, r_weight=10.0):
+    """ILQR + FullBicycle{Kinematic,Dynamic}Node with the converging (soft) weights.  The reference reproduces its own
+    solves (from a start state moved by 1e-13) for the dynamic node at H = 100 and for the kinematic node at H = 20
+    (the horizon of cilqr/test_full.py:28-59) or, at H = 50, with r_weight = 100."""
     k = 0.0 if model == "kin" else 1e-3
     desc = capi.make_problem(model, "legacy", H, B, L=3.0, dt=0.1, v=10.0, k=k)
     Q = np.diag([1e-1, 1e-1, 1.0, 1e-9, 1e-6, 1e-6])
-    R = np.eye(2) * 10.0
+    R = np.eye(2) * float(r_weight)
     cons = capi.pack_box([-1000, -1000, -2 * np.pi, -10, -100, -10.0], [1000, 1000, 2 * np.pi, 10, 100, 10.0],
                          [-0.2, -1.0], [0.2, 1.0])
     if x0 is None:
@@ -162,17 +164,21 @@ def kin_linear(B, H=50, seed=1, y_max=23.5):
     return desc, full_start_states(B, seed), s_curve_goals(10.0, 0.1, H, True), Q, R, capi.pack_linear(A, Bm, C)
 
 
-def fast_box_linear(B, H=100, seed=2):
-    """FastILQR + FastBicycleNode with the box of cilqr/test_fast_full.py:31-60 stacked with two extra
-    half-plane rows (y <= 40, active near the crest of the S-curve, and y >= -5): a linear table of 18 rows."""
+def fast_box_linear(B, H=100, seed=2, stiff=False):
+    """Benchmark configuration 4b: FastILQR + FastBicycleNode with the box of cilqr/test_fast_full.py:31-60 stacked
+    with two extra half-plane rows (y <= 40, active near the crest of the S-curve, and y >= -5): a linear table of 18
+    rows.  Weights and wheel base are the converging ones of al_ilqr_test.cc:33-35 (Q un-scaled, R = 10 I, L = 3), on
+    which the reference reproduces its own H = 100 solves (tests/golden/fast_box_linear_h100.npz, 30 of 32).
+    ``stiff``: the shipped weights of test_fast_full.py (Q * 1e3, R = 100 I, L = 1), on which neither the reference nor
+    anything else reproduces a solve from a start state moved by 1e-13; kept as a named property-test workload."""
     A, Bm, C = box_table([-1000, -1000, -2 * np.pi, -10, -100, -10.0], [1000, 1000, 2 * np.pi, 10, 100, 10.0],
                          [-0.2, -1.0], [0.2, 1.0])
     A = np.vstack([A, [[0, 1.0, 0, 0, 0, 0], [0, -1.0, 0, 0, 0, 0]]])
     Bm = np.vstack([Bm, np.zeros((2, 2))])
     C = np.concatenate([C, [-40.0, -5.0]])
-    desc = capi.make_problem("dyn_mid", "fast", H, B, L=1.0, dt=0.1, v=10.0, k=0.001, c=A.shape[0])
-    Q = np.diag([1e-1, 1e-1, 1.0, 1e-9, 1e-6, 1e-6]) * 1e3
-    R = np.eye(2) * 1e2
+    desc = capi.make_problem("dyn_mid", "fast", H, B, L=1.0 if stiff else 3.0, dt=0.1, v=10.0, k=0.001, c=A.shape[0])
+    Q = np.diag([1e-1, 1e-1, 1.0, 1e-9, 1e-6, 1e-6]) * (1e3 if stiff else 1.0)
+    R = np.eye(2) * (1e2 if stiff else 10.0)
     return desc, full_start_states(B, seed), s_curve_goals(10.0, 0.1, H, True), Q, R, capi.pack_linear(A, Bm, C)
 
 

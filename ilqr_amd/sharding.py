@@ -102,8 +102,8 @@ def solve_batch_sharded(desc, x0, goals, Q, R, cons, u_offset=None, starts_per_s
         dev = device or f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
 
         def solver(dd, xx, gg, Qq, Rr, cc, u_offset=None, **k2):
-            if dd.batch == 0:
-                return _empty_like_outputs(dd, dev)
+            # an empty shard (more ranks than problems) goes the same way: solve_batch returns every output of the
+            # call with zero rows, so all ranks hold the same keys for the gather below
             return _batch.solve_batch(dd, xx, gg, Qq, Rr, cc, device=dev, u_offset=u_offset, **k2)
     out = solver(d, x0_l, goals_l, Q, R, cons, u_offset=uo_l, **kw)
     out = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(v)) for k, v in out.items()}
@@ -123,14 +123,22 @@ def solve_batch_sharded(desc, x0, goals, Q, R, cons, u_offset=None, starts_per_s
         n_scen = B // starts_per_scenario
         for k in ("best_cost", "best_start", "best_x", "best_u"):
             res[k] = gather_rows(res[k], n_scen, group)
-    for k, v in out.items():
-        res[k] = gather_rows(v, B, group)
+    # every rank must issue the same collectives in the same order: gather over the sorted key list, after checking
+    # that all ranks hold the same one (a solver that returns other outputs for an empty shard would deadlock here)
+    keys = sorted(out)
+    _check_same_keys(keys, out[keys[0]].device if keys else "cpu", group)
+    for k in keys:
+        res[k] = gather_rows(out[k], B, group)
     return res
 
 
-def _empty_like_outputs(d, dev):
+def _check_same_keys(keys, device, group=None):
+    import zlib
     import torch
-    f64 = dict(dtype=torch.float64, device=dev)
-    H, n, m = d.horizon, d.n, d.m
-    return dict(x=torch.empty((0, H + 1, n), **f64), u=torch.empty((0, H, m), **f64), cost=torch.empty((0,), **f64),
-                status=torch.zeros((0, 4), dtype=torch.int32, device=dev))
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mine = torch.tensor([len(keys), zlib.crc32(",".join(keys).encode())], dtype=torch.int64, device=device)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    if any(not torch.equal(t, mine) for t in every):
+        raise RuntimeError("ranks returned different sets of outputs from their shard solves; cannot gather")

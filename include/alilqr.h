@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ALILQR_ABI_VERSION 5
+#define ALILQR_ABI_VERSION 6
 
 /* ---- vehicle model (node type) ------------------------------------------
  * LAT      4 states / 1 control   cilqr/lat_bicycle_node.py:4-91
@@ -85,6 +85,7 @@ enum alilqr_status {
 #define ALILQR_FLAG_VIOL_OK   1u   /* stopped because violation < viol_stop           */
 #define ALILQR_FLAG_OUTER_CAP 2u   /* ran out of outer iterations                     */
 #define ALILQR_FLAG_NONFINITE 4u   /* final cost is NaN/Inf (the reference is silent) */
+#define ALILQR_FLAG_STOPPED   8u   /* ended by alilqr_extras::stop_after, not by a stop rule of the reference */
 
 /* Solver constants.  The reference hard-codes these as literals; the defaults
  * returned by alilqr_default_params() are those literals, per generation:
@@ -243,6 +244,14 @@ typedef struct alilqr_extras {
   double* mu_solver_out;
   const int32_t* first_rows;
   double* overlay_out;
+  /* Diagnostic (no counterpart in the reference): stop_after [B] or NULL.  Problem b with stop_after[b] = k > 0 ends
+   * right after its k-th inner iteration (counted over the whole solve, as the trace counts them): no violation
+   * measure, multiplier or penalty update follows.  node_x / node_u / cost are then the nodes' trajectory and its cost
+   * after that iteration's forward() (cilqr/ilqr.py:160, fast_ilqr.py:145, new_al_ilqr.h:1104), x_out / u_out the pair
+   * optimize() would hold at that point, status[1] the outer iterations completed before, status[2] carries
+   * ALILQR_FLAG_STOPPED.  A solve that ends earlier by its own rules is not affected.  Lets a test compare the
+   * iterate of a chosen iteration with the reference's instead of only the end of the solve. */
+  const int32_t* stop_after;
 } alilqr_extras;
 
 /* alilqr_solve_batch with the optional inputs above (ex may be NULL). */

@@ -771,6 +771,8 @@ static int py_optimize(const alilqr_problem* p, or_node* nodes,
   uint32_t flags = 0;
   double violation = 0.0;
   if (trace) trace->length = 0;
+  const int stop_k = (or_extras && or_extras->stop_after) ? or_extras->stop_after[or_problem] : 0;
+  int stopped = 0;
   for (int j = 0; j < p->prm.max_outer; ++j) {
     old_cost = compute_total_cost(&s);
     for (int i = 0; i < p->prm.max_inner; ++i) {
@@ -788,10 +790,15 @@ static int py_optimize(const alilqr_problem* p, or_node* nodes,
         double sc = fmax(fabs(new_cost), fabs(old_cost));
         or_decision(sc + (fabs(new_cost - old_cost) - p->prm.inner_tol), sc);
       }
-      if (fabs(new_cost - old_cost) < p->prm.inner_tol) break;
-      x = nx; u = nu; gen = g;
-      old_cost = new_cost;
+      const int brk = fabs(new_cost - old_cost) < p->prm.inner_tol;
+      if (!brk) {
+        x = nx; u = nu; gen = g;
+        old_cost = new_cost;
+      }
+      if (stop_k > 0 && s.n_inner >= stop_k) { stopped = 1; break; }   /* alilqr_extras::stop_after */
+      if (brk) break;
     }
+    if (stopped) { flags |= ALILQR_FLAG_STOPPED; break; }
     violation = compute_violation(&s);
     ++n_outer;
     or_decision(violation, p->prm.viol_stop);
@@ -805,7 +812,7 @@ static int py_optimize(const alilqr_problem* p, or_node* nodes,
       for (int t = 0; t <= H; ++t) nodes[t].mu = nodes[t].mu * p->prm.mu_gain;
     }
   }
-  if (!(flags & ALILQR_FLAG_VIOL_OK)) flags |= ALILQR_FLAG_OUTER_CAP;
+  if (!(flags & (ALILQR_FLAG_VIOL_OK | ALILQR_FLAG_STOPPED))) flags |= ALILQR_FLAG_OUTER_CAP;
   if (x_out) memcpy(x_out, x, sizeof(double) * xs);
   if (u_out) memcpy(u_out, u, sizeof(double) * us);
   if (x_init_o) memcpy(x_init_o, x_init, sizeof(double) * xs);

@@ -694,6 +694,8 @@ int32_t or_new_solve(const alilqr_problem* p,
   uint32_t flags = 0;
   double violation = 0.0;
   if (trace) trace->length = 0;
+  const int stop_k = (or_extras && or_extras->stop_after) ? or_extras->stop_after[or_problem] : 0;
+  int stopped = 0;
   for (int outer = 0; outer < p->prm.max_outer; ++outer) {
     for (int iter = 0; iter < p->prm.max_inner; ++iter) {          /* ILQRProcess :1090-1122 */
       nw_update_constraints(&s);
@@ -713,8 +715,10 @@ int32_t or_new_solve(const alilqr_problem* p,
         or_decision(sc + ((old_cost - new_cost) - p->prm.inner_tol), sc);
         or_decision(old_cost, new_cost);
       }
+      if (stop_k > 0 && s.n_inner >= stop_k) { stopped = 1; break; }   /* alilqr_extras::stop_after */
       if ((old_cost - new_cost < p->prm.inner_tol) && ((old_cost - new_cost) >= 0)) break;
     }
+    if (stopped) { flags |= ALILQR_FLAG_STOPPED; break; }
     double zero_u[OR_NU] = {0};
     violation = 0.0;                                                /* :1081-1087 */
     for (int t = 0; t <= H; ++t) {
@@ -732,7 +736,7 @@ int32_t or_new_solve(const alilqr_problem* p,
       for (int t = 0; t <= H; ++t) nw_update_lambda(&s.nodes[t], s.x + (size_t)t * n, (t < H) ? s.u + (size_t)t * m : zero_u);
     }
   }
-  if (!(flags & ALILQR_FLAG_VIOL_OK)) flags |= ALILQR_FLAG_OUTER_CAP;
+  if (!(flags & (ALILQR_FLAG_VIOL_OK | ALILQR_FLAG_STOPPED))) flags |= ALILQR_FLAG_OUTER_CAP;
   /* final AL cost of the returned trajectory under the final multipliers */
   double total = 0.0, zero_u[OR_NU] = {0};
   for (int t = 0; t <= H; ++t) total += nw_cost(&s.nodes[t], s.x + (size_t)t * n, (t < H) ? s.u + (size_t)t * m : zero_u);

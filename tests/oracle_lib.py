@@ -36,7 +36,7 @@ def _p(a):
 
 
 def solve_batch(desc, x0, goals, Q, R, cons, threads=0, extras=True, u_offset=None, left_obs=None, right_obs=None,
-                first_row=0, mu_solver=None, first_rows=None, overlay=False):
+                first_row=0, mu_solver=None, first_rows=None, overlay=False, stop_after=None):
     """Run the oracle on a batch; arrays are host numpy float64, C-contiguous.  With ``extras`` the result also holds
     ``margin`` [B]: the smallest relative distance between the two sides of any accept / reject / stop comparison
     the solve made (a solve with a margin at rounding level is decided by rounding)."""
@@ -60,6 +60,9 @@ def solve_batch(desc, x0, goals, Q, R, cons, threads=0, extras=True, u_offset=No
     if overlay:
         out["overlay"] = np.zeros((B, H + 1, 2 * c + 1))
         ex.overlay_out = out["overlay"].ctypes.data
+    if stop_after is not None:
+        sa = np.ascontiguousarray(np.broadcast_to(np.asarray(stop_after, dtype=np.int32), (B,)))
+        ex.stop_after = sa.ctypes.data
     margin = np.ones(B) if extras else None
     lib().oracle_set_margin_out(_p(margin))
     rc = lib().oracle_solve_batch_ex(C.byref(desc), *[_p(a) for a in args], C.byref(ex),

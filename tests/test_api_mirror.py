@@ -51,26 +51,20 @@ def test_legacy_node_data_helpers():
     assert np.array_equal(nd.constraint_table(), capi.pack_box(nd.state_min, nd.state_max, nd.control_min, nd.control_max))
 
 
-def test_constraints_scalar_helpers_follow_the_reference_formulas():
-    rng = np.random.default_rng(0)
-    A, B, C = rng.normal(size=(5, 6)), rng.normal(size=(5, 2)), rng.normal(size=5)
-    cons = LinearConstraints(A, B, C)
-    cons.lambda_ = -np.abs(rng.normal(size=5)); cons.mu = 2.5
-    x, u = rng.normal(size=6), rng.normal(size=2)
-    c = A @ x + B @ u + C
-    f = cons.lambda_ - 2.5 * c
-    lp = np.minimum(f, 0)
-    assert abs(cons.augmented_lagrangian_cost(x, u) - 0.5 / 2.5 * (lp @ lp - cons.lambda_ @ cons.lambda_)) < 1e-14
-    dx, du = cons.augmented_lagrangian_jacobian(x, u)
-    pj = np.diag((f <= 0).astype(float))
-    assert np.allclose(dx, -(pj @ A).T @ lp) and np.allclose(du, -(pj @ B).T @ lp)
-    hx, hu, hxu = cons.augmented_lagrangian_hessian(x, u)
-    assert np.allclose(hx, 2.5 * (pj @ A).T @ (pj @ A)) and hxu.shape == (6, 2) and hu.shape == (2, 2)
-    assert abs(cons.max_violation(x, u) - max(0, c.max())) < 1e-15
-    cons.update_lambda()
-    assert np.allclose(cons.lambda_, lp)
+def test_constraints_objects_hold_tables_and_refuse_host_evaluation():
     box = BoxConstraint(-np.ones(3), np.ones(3), -np.ones(2) / 2, np.ones(2) / 2)
     assert box.A.shape == (10, 3) and box.B.shape == (10, 2) and np.allclose(box.C, [-1, -1, -1, -1, -1, -1, -.5, -.5, -.5, -.5])
+    assert np.array_equal(box.projection(np.array([1.0, -2.0])), [0.0, -2.0])
+    # a 3-state table has no GPU node kernel in this generation: the AL calls say so instead of computing on the host
+    with pytest.raises(NotImplementedError):
+        box.augmented_lagrangian_cost(np.zeros(3), np.zeros(2))
+
+    class Mine(Constraints):
+        def constrains(self, x, u): return x
+        def constrains_jacobian(self, x, u): return None, None
+        def constrains_hessian(self, x, u): return None, None, None
+    with pytest.raises(NotImplementedError):
+        Mine(2).max_violation(np.zeros(2), np.zeros(1))
 
 
 def test_solver_describes_the_node_list():

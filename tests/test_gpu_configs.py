@@ -24,27 +24,24 @@ def worst_err(o, ref, i):
     return gu.solve_err(o, ref, i)
 
 
-def stable_mask(prob, ref, u_offset=None, probes=2):
-    desc, x0 = prob[0], prob[1]
-    rng = np.random.default_rng(4)
-    scale = np.zeros(x0.shape[1]); scale[1:3] = 1e-13
-    ok = np.ones(desc.batch, dtype=bool)
-    for _ in range(probes):
-        ref2 = ol.solve_batch(desc, x0 + rng.uniform(-1, 1, size=x0.shape) * scale, *prob[2:6], u_offset=u_offset)
-        ok &= np.array([worst_err(ref2, ref, i) < 1e-8 for i in range(desc.batch)])
-    return ok
+def stable_mask(prob, ref, u_offset=None, probes=4):
+    """Solves the oracle reproduces to 1e-8 from `probes` start states moved by ~1e-13."""
+    kw = {} if u_offset is None else dict(u_offset=u_offset)
+    return gu.oracle_stable_mask(prob, ref, probes=probes, seed=4, **kw)
 
 
 CASES = {
     # name: (generator, fraction of solves that must be pinned, compare iteration counts)
-    "kin_linear_new_al": (lambda: problems.kin_linear(48), 0.5, True),
-    "dyn_legacy_h100": (lambda: problems.full_legacy("dyn", 32, 100, 2), 0.5, True),
-    # FastILQR stops its inner loop on |dJ| < 1e-8, i.e. on rounding noise of a cost of 1e4: results are
-    # pinned, iteration counts are not
+    "kin_linear_new_al": (lambda: problems.kin_linear(48), 0.6, True),
+    "dyn_legacy_h100": (lambda: problems.full_legacy("dyn", 32, 100, 2), 0.9, True),
+    # FastILQR stops its inner loop on |dJ| < 1e-8, i.e. on rounding noise of the cost: results are pinned,
+    # iteration counts are not.  Benchmark configuration 4b is the H = 100 case (converging weights, see
+    # problems.fast_box_linear; reference vectors in tests/golden/fast_box_linear_h100.npz).
     "fast_box_plus_linear_h50": (lambda: problems.fast_box_linear(32, H=50), 0.8, False),
-    # at H = 100 the same solver is ill-conditioned enough that the oracle reproduces few of its own solves to
-    # 1e-8; those few are held to 1e-6, the rest to agreement of the converged cost
-    "fast_box_plus_linear_h100": (lambda: problems.fast_box_linear(32), 0.0, False),
+    "fast_box_plus_linear_h100": (lambda: problems.fast_box_linear(32), 0.75, False),
+    # PROPERTY TEST, not parity: the shipped demo weights (Q * 1e3, L = 1) at H = 100, on which nothing - the reference
+    # included - reproduces a solve from a start state moved by 1e-13; held to the stopping state and the converged cost
+    "fast_box_plus_linear_h100_stiff_weights": (lambda: problems.fast_box_linear(32, stiff=True), 0.0, False),
 }
 
 
@@ -85,7 +82,7 @@ def test_multi_start_matches_oracle_and_picks_the_same_winner(mode):
     assert np.array_equal(o["x"][::starts], base["x"][::starts])
     assert np.abs(o["u_init"][1] - o["u_init"][0]).max() > 1e-3
     ok = stable_mask(prob, ref, u_offset=uo)
-    assert gu.pinned(f"configs/multi_start/{mode}", ok) >= (0.8 if mode == "new_al" else 0.3)
+    assert gu.pinned(f"configs/multi_start/{mode}", ok) >= 0.9
     for i in np.nonzero(ok)[0]:
         assert worst_err(o, ref, i) < TOL, (mode, i)
     # arg-min over the starts of a scenario: same best cost where every start of the scenario is pinned

@@ -57,9 +57,7 @@ def check_full_batch(prob, kw, floor, u_offset=None, seed=0):
         assert np.array_equal(alone[k], full[k][idx], equal_nan=True), k
 
     ref = ol.solve_batch(*sub, u_offset=uo, **kw)
-    bump = np.zeros_like(sub[1]); bump[:, 1] = 1e-13
-    ref2 = ol.solve_batch(sub[0], sub[1] + bump, *sub[2:6], u_offset=uo, **kw)
-    ok = np.array([worst_err(ref2, ref, i) < 1e-8 for i in range(SAMPLE)])
+    ok = gu.oracle_stable_mask(sub, ref, probes=4, seed=3, **({} if uo is None else dict(u_offset=uo)), **kw)
     assert gu.pinned(f"full_sizes/sample of {full['cost'].shape[0]} ({sub[0].model}/{sub[0].mode})", ok) >= floor
     for i in np.nonzero(ok)[0]:
         assert worst_err(alone, ref, i) < TOL, (i, idx[i], alone["status"][i], ref["status"][i])
@@ -68,7 +66,7 @@ def check_full_batch(prob, kw, floor, u_offset=None, seed=0):
 
 def test_config3_kinematic_rectangles_batch_65536():
     prob, kw = problems.kin_rect(65536)
-    full = check_full_batch(prob, kw, 0.6)
+    full = check_full_batch(prob, kw, 0.8)
     # the rest stops at the outer-iteration cap (rows activated by the rectangles keep the violation above 1e-3)
     assert ((full["status"][:, 2] & capi.FLAG_VIOL_OK) != 0).mean() > 0.3
 
@@ -76,9 +74,9 @@ def test_config3_kinematic_rectangles_batch_65536():
 @pytest.mark.parametrize("gen", ["legacy", "fast_box_linear"])
 def test_config4_dynamic_h100_batch_16384(gen):
     if gen == "legacy":
-        prob, floor = problems.full_legacy("dyn", 16384, 100, 2), 0.4
+        prob, floor = problems.full_legacy("dyn", 16384, 100, 2), 0.9
     else:
-        prob, floor = problems.fast_box_linear(16384), 0.0
+        prob, floor = problems.fast_box_linear(16384), 0.85
     check_full_batch(prob, {}, floor)
 
 
@@ -86,7 +84,7 @@ def test_config5_multi_start_256_starts_1024_scenarios():
     scen, starts = 1024, 256
     desc, x0, goals, Q, R, cons, uo = problems.multi_start(scen, starts)
     prob = (desc, x0, goals, Q, R, cons)
-    full = check_full_batch(prob, {}, 0.8, u_offset=uo)
+    full = check_full_batch(prob, {}, 0.9, u_offset=uo)
     # start 0 of every scenario carries no perturbation: same bits as the plain solve of the 1024 scenarios
     base, _ = subset(prob, np.arange(0, scen * starts, starts))
     plain = to_np(batch.solve_batch(*base, extras=False))

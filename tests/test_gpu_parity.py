@@ -49,29 +49,66 @@ def lanes(request, tuning):
     return int(request.param)
 
 
-@pytest.mark.parametrize("name", ["lat_legacy", "dyn_legacy", "kin_legacy", "fast_box", "fast_linear", "fast_equality",
-                                  "lon_legacy", "interior_legacy"])
+GOLDEN_SETS = ["lat_legacy", "dyn_legacy", "kin_legacy", "kin_legacy_h50", "fast_box", "fast_linear", "fast_box_linear_h100",
+               "fast_equality", "lon_legacy", "interior_legacy"]
+# share of a set's solves that must be held to 1e-6 at the END of the solve against the reference's own vectors
+END_FLOOR = {"lat_legacy": 0.8, "dyn_legacy": 0.8, "kin_legacy": 0.9, "kin_legacy_h50": 0.7, "fast_box": 0.1, "fast_linear": 0.9,
+             "fast_box_linear_h100": 0.8, "fast_equality": 0.9, "lon_legacy": 0.7, "interior_legacy": 0.7}
+PROBES = 8
+_ORACLE_CACHE = {}
+
+
+def _oracle_side(name, prob, g):
+    """Oracle results of a golden set (computed once per session): the solve, its per-iteration trace, and the mask of
+    solves it reproduces to 1e-8 from PROBES start states moved by ~1e-13 in random directions."""
+    if name not in _ORACLE_CACHE:
+        ref = ol.solve_batch(*prob)
+        cost, trials = ol.solve_batch_traced(*prob, capacity=1024)
+        probe = gu.oracle_stable_mask(prob, ref, probes=PROBES, keys=("x", "u", "node_x", "node_u"))
+        _ORACLE_CACHE[name] = (ref, cost, trials, probe)
+    return _ORACLE_CACHE[name]
+
+
+def _gpu_stopped(sub, stop, **kw):
+    return to_np(batch.solve_batch(*sub, stop_after=stop, **kw))
+
+
+@pytest.mark.parametrize("name", GOLDEN_SETS)
 def test_golden_sets(name, lanes):
-    """GPU vs the reference's own vectors and vs the oracle, every lane-group width."""
+    """GPU vs the reference's own vectors and vs the oracle, every lane-group width.  EVERY solve of a set gets a 1e-6
+    assertion:
+      * at the END of the solve, against the reference's vectors and the oracle, when the reference reproduced the solve
+        from a moved start state (golden `stable`) and the oracle reproduces it from eight more, or the GPU simply took
+        the same decisions as the oracle (equal iteration, outer-iteration and roll-out counts);
+      * otherwise - a solve whose end neither the reference nor the oracle reproduces: a late line search between costs
+        equal to the last bit, iterates that amplify one rounding error - at the last inner iteration up to which the
+        GPU's and the oracle's traces agree, on the iterate itself (fast_box, the reference's own demo weights: all but
+        two or three of its 16 solves are of that kind);
+      * sets that hold the reference's own mid-solve iterates (fast_box, fast_box_linear_h100): against those as well."""
     g = gu.load(name)
-    desc, x0, goals, Q, R, cons = gu.problem_from_golden(g)
-    ref = ol.solve_batch(desc, x0, goals, Q, R, cons)
-    o = to_np(batch.solve_batch(desc, x0, goals, Q, R, cons))
-    # pinned = the reference reproduced itself from one moved start state (recorded with the vectors) AND the oracle
-    # reproduces itself from three more: a solve that sits on a line-search decision boundary can pass one probe
-    stable = g["stable"] & gu.oracle_stable_mask((desc, x0, goals, Q, R, cons), ref, keys=("x", "u", "node_x", "node_u"))
-    stable, loose = gu.split_pinned(o, ref, stable)
-    # (fast_box: every solve ends each outer iteration with a line search between costs that are equal to the last
-    #  bit, so none is strict; tests/test_gpu_trace.py holds those to the oracle iteration by iteration instead)
-    gu.pinned(f"golden/{name}/lanes={lanes}", stable)
-    assert stable.sum() + loose.sum() >= 3 and (stable.sum() >= 3 or name == "fast_box")
-    for i in np.nonzero(loose)[0]:           # decided by rounding, and decided differently: same answer to 1e-3
-        assert worst_err(o, ref, i) < 1e-3, (name, i, "vs oracle, loose")
-    for i in np.nonzero(stable)[0]:
+    prob = gu.problem_from_golden(g)
+    B = prob[0].batch
+    ref, or_cost, or_trials, probe = _oracle_side(name, prob, g)
+    o = to_np(batch.solve_batch(*prob, trace=1024))
+    same = (o["status"] == ref["status"]).all(axis=1)
+    at_end = np.asarray(g["stable"], dtype=bool) & (probe | same)
+    frac = gu.pinned(f"golden/{name}/lanes={lanes}: end of solve vs reference vectors", at_end)
+    assert frac >= END_FLOOR[name], (name, frac)
+    gold = {k: g[k] for k in KEYS + ("cost",)}
+    for i in np.nonzero(at_end)[0]:
+        assert worst_err(o, gold, i) < TOL, (name, i, "vs reference vectors", worst_err(o, gold, i))
         assert worst_err(o, ref, i) < TOL, (name, i, "vs oracle")
-        assert worst_err(o, {k: g[k] for k in KEYS + ("cost",)}, i) < TOL, (name, i, "vs reference vectors")
         assert gu.rel_err(o["lam"][i], ref["lam"][i]) < TOL
         assert o["status"][i, 1] == ref["status"][i, 1]
+    rest = np.nonzero(~at_end)[0]
+    gu.mid_solve_check(f"golden/{name}/lanes={lanes}", prob, rest, o["trials"], o["iter_cost"], o["status"][:, 0],
+                       or_trials, or_cost, _gpu_stopped, ol.solve_batch)
+    # the end of those solves is still a converged answer of the same problem: costs agree to 1e-3 where both are finite
+    for i in rest:
+        if np.isfinite(o["cost"][i]) and np.isfinite(ref["cost"][i]) and g["stable"][i]:
+            assert abs(o["cost"][i] - ref["cost"][i]) <= 1e-3 * max(1.0, abs(ref["cost"][i])), (name, i, "final cost")
+    if "snap_iters" in g.files:
+        gu.check_iterates(g, f"{name}/lanes={lanes}", lambda stop: _gpu_stopped(prob, stop), o["trials"], o["iter_cost"], "gpu")
 
 
 def test_node_evaluation_kernel_matches_reference_vectors():

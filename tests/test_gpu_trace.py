@@ -23,9 +23,11 @@ CAP = 512
 SETS = {
     "lat_legacy": lambda: problems.lat_legacy(96, 50, seed=0),
     "dyn_legacy_h100": lambda: problems.full_legacy("dyn", 16, 100, 2),
-    "kin_legacy": lambda: problems.full_legacy("kin", 24, 50, 1),
+    "kin_legacy_h20": lambda: problems.full_legacy("kin", 24, 20, 1),
+    "kin_legacy_h50": lambda: problems.full_legacy("kin", 24, 50, 1, r_weight=100.0),
     "fast_box": lambda: problems.fast_box(24),
     "fast_box_linear_h100": lambda: problems.fast_box_linear(12),
+    "fast_box_linear_h100_stiff_weights": lambda: problems.fast_box_linear(12, stiff=True),
     "new_al_box6_active_bound": lambda: problems.new_al_box(32, y_max=20.0),
     "new_al_circle4": lambda: problems.new_al_lat_circle(32),
     "new_al_circle6": lambda: problems.new_al_circle(32),

@@ -12,7 +12,8 @@ import oracle_lib as ol
 from ilqr_amd import capi
 
 TOL = 1e-6
-SETS = ["lat_legacy", "dyn_legacy", "kin_legacy", "fast_box", "fast_linear", "fast_equality", "lon_legacy", "interior_legacy"]
+SETS = ["lat_legacy", "dyn_legacy", "kin_legacy", "kin_legacy_h50", "fast_box", "fast_linear", "fast_box_linear_h100",
+        "fast_equality", "lon_legacy", "interior_legacy"]
 
 
 @pytest.mark.parametrize("name", SETS)
@@ -32,6 +33,17 @@ def test_solver_matches_reference_on_stable_problems(name):
         if name != "fast_box":
             # fast_box: the reference's BLAS rounding moves a few accept/reject ties, results agree anyway
             assert out["status"][i, 0] == g["n_inner"][i], (name, i, "inner iterations")
+
+
+@pytest.mark.parametrize("name", ["fast_box", "fast_box_linear_h100"])
+def test_mid_solve_iterates_match_reference(name):
+    """The reference's node trajectory after chosen inner iterations (stored for the first solves of these sets) against
+    the oracle stopped at the same iteration - also for solves whose LAST line searches are decided by rounding."""
+    g = gu.load(name)
+    prob = gu.problem_from_golden(g)
+    cost, trials = ol.solve_batch_traced(*prob, capacity=1024)
+    n, mean_it = gu.check_iterates(g, name, lambda stop: ol.solve_batch(*prob, stop_after=stop), trials, cost, "oracle")
+    assert n >= 7 and mean_it >= 8
 
 
 def test_config1_headline_numbers():

@@ -73,7 +73,7 @@ def _standin_solver(desc, x0, goals, Q, R, cons, u_offset=None, **kw):
     u = np.zeros((B, H, m)) + x0[:, :1, None]
     if u_offset is not None:
         u = u + np.asarray(u_offset).reshape(B, H, m)
-    cost = (x0 ** 2).sum(axis=1) + (0.0 if u_offset is None else np.abs(np.asarray(u_offset).reshape(B, -1)).sum(axis=1))
+    cost = (x0 ** 2).sum(axis=1) + (0.0 if u_offset is None else np.abs(np.asarray(u_offset).reshape(B, H * m)).sum(axis=1))
     status = np.tile(np.array([[3, 1, 1, 7]], dtype=np.int32), (B, 1))
     return dict(x=torch.as_tensor(x), u=torch.as_tensor(u), cost=torch.as_tensor(cost), status=torch.as_tensor(status))
 
@@ -101,7 +101,9 @@ def _sharded_worker(rank, world, port, B, starts, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B,starts", [(13, None), (24, 4), (20, 4)])
+# (1, None) and (4, 4): fewer problems (scenarios) than ranks, rank 1 solves an empty shard and still takes part in
+# every collective of the gather
+@pytest.mark.parametrize("B,starts", [(13, None), (24, 4), (20, 4), (1, None), (4, 4)])
 def test_solve_batch_sharded_two_ranks(B, starts):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -139,3 +141,40 @@ def test_solve_batch_sharded_single_process_is_the_plain_solve():
     assert res["range"] == (0, 9) and np.array_equal(res["cost"].numpy(), want["cost"].numpy())
     bc, bi = sharding.best_start(want["cost"].numpy(), 3)
     assert np.array_equal(res["best_start"].numpy(), bi)
+
+
+def _uneven_solver(desc, *a, **kw):
+    out = _standin_solver(desc, *a, **kw)
+    if desc.batch == 0:
+        out.pop("status")            # a solver that returns fewer outputs for an empty shard
+    return out
+
+
+def _uneven_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    desc, x0, goals, Q, R, cons, uo = _sharded_inputs(1)
+    try:
+        sharding.solve_batch_sharded(desc, x0, goals, Q, R, cons, solver=_uneven_solver)
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_with_different_outputs_raise_instead_of_deadlocking():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all("different sets of outputs" in msg for msg in got.values()), got

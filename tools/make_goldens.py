@@ -11,14 +11,21 @@ Usage:  MPLBACKEND=Agg python tools/make_goldens.py [--only NAME] [--jobs 8]
 Sets written to tests/golden/:
   nodes_kat.npz         per-call known answers of the node / constraint functions
   lat_legacy.npz        ILQR + LatBicycleKinematicNode (x0 = 0 case first, then rng(0) cases)
-  kin_legacy.npz        ILQR + FullBicycleKinematicNode, soft weights, H=50
+  kin_legacy.npz        ILQR + FullBicycleKinematicNode, soft weights, H=20 (the horizon of cilqr/test_full.py:28-59;
+                        at H=50 the reference does not reproduce its own kinematic solves from a start state moved by 1e-13)
+  kin_legacy_h50.npz    the same node at H=50 with R = 100 I, on which most solves are reproducible
   dyn_legacy.npz        ILQR + FullBicycleDynamicNode,   soft weights, H=100
   fast_box.npz          FastILQR + FastBicycleNode + BoxConstraint (test_fast_full.py setup)
   fast_linear.npz       FastILQR + FastBicycleNode(k=0) + LinearConstraints (box rows + half-planes)
+  fast_box_linear_h100.npz  FastILQR + FastBicycleNode + the box stacked with two half-plane rows, H=100 (benchmark
+                        configuration 4b), soft weights
   fast_equality.npz     FastILQR + FastBicycleNode(k=0) + LinearConstraints(is_equality=True)
   lon_legacy.npz        ILQR + LongitudinalNode (triple integrator, active control / acceleration bounds)
   interior_legacy.npz   ILQR + LatBicycleInteriorNode (tanh-squashed steering rate, state bounds only)
   nodes_kat_extra.npz   per-call known answers of those two nodes
+fast_box and fast_box_linear_h100 also hold the node trajectory of their first SNAP_SOLVES solves after the inner
+iterations SNAP_ITERS (snap_iters, snap_x, snap_u, snap_cost): a test can then compare an iterate in the middle of a
+solve, before the first line search that rounding decides.
 """
 import argparse
 import contextlib
@@ -176,6 +183,20 @@ def fast_linear_problem(H=50):
     return p
 
 
+def fast_box_linear_problem(H=100):
+    """Benchmark configuration 4b: the dynamic fast node (k = 1e-3) with the box of cilqr/test_fast_full.py:31-60 as a
+    linear table, stacked with two half-plane rows (y <= 40, active near the crest of the S-curve, and y >= -5): 18
+    rows.  Soft weights and L = 3 (al_ilqr_test.cc:33-35): with the shipped Q * 1e3, L = 1 the reference does not
+    reproduce its own H = 100 solves from a start state moved by 1e-13."""
+    p = full_problem("dyn_mid", H, mode="fast")
+    A, Bm, C = box_to_linear(p)
+    A = np.vstack([A, [[0, 1.0, 0, 0, 0, 0], [0, -1.0, 0, 0, 0, 0]]])
+    Bm = np.vstack([Bm, np.zeros((2, 2))])
+    C = np.concatenate([C, [-40.0, -5.0]])
+    p.update(A=A, B=Bm, C=C)
+    return p
+
+
 def fast_equality_problem(H=50):
     """kinematic (k=0) fast node with an EQUALITY table (LinearConstraints(..., is_equality=True)):
     jerk u1 = 0 and steering rate u0 = -0.5 * steering angle.  Both rows can be met at every node."""
@@ -191,6 +212,9 @@ def fast_equality_problem(H=50):
 # ----------------------------------------------------------------------------
 # traced solver runs
 # ----------------------------------------------------------------------------
+SNAP_ITERS = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256)   # inner iterations whose iterate is kept
+SNAP_SOLVES = 8                                                              # ... of the first solves of a set
+
 def _make_traced(base):
     class Traced(base):
         def __init__(self, nodes):
@@ -201,6 +225,7 @@ def _make_traced(base):
             self.trials = []
             self.iter_cost = []
             self.viol = []
+            self.snaps = {}
 
         def compute_total_cost(self):
             if self.in_forward:
@@ -218,6 +243,10 @@ def _make_traced(base):
             self.in_forward = False
             self.trials.append(self.n_cost_calls - 1)
             self.iter_cost.append(float(super().compute_total_cost()))
+            if len(self.trials) in SNAP_ITERS:
+                self.snaps[len(self.trials)] = (np.array([nd.state for nd in self.ilqr_nodes], dtype=float),
+                                                np.array([nd.control for nd in self.ilqr_nodes[:-1]], dtype=float),
+                                                self.iter_cost[-1])
             return out
 
         def compute_constrain_violation(self):
@@ -283,10 +312,10 @@ def solve_one(args):
         node_x=np.array([nd.state for nd in nodes], dtype=float),
         node_u=np.array([nd.control for nd in nodes[:-1]], dtype=float),
         cost=cost, lam=lam, mu=mu, n_inner=s.n_inner, n_outer=len(s.viol),
-        trials=np.array(s.trials), iter_cost=np.array(s.iter_cost), viol=np.array(s.viol), wall=wall)
+        trials=np.array(s.trials), iter_cost=np.array(s.iter_cost), viol=np.array(s.viol), wall=wall, snaps=s.snaps)
 
 
-def run_set(name, p, x0s, jobs):
+def run_set(name, p, x0s, jobs, snaps=False):
     import multiprocessing as mp
     t0 = time.time()
     x0s = list(x0s)
@@ -336,6 +365,17 @@ def run_set(name, p, x0s, jobs):
     out["viol"] = pad("viol", maxo)
     out["ref_wall_s"] = np.array([r["wall"] for r in res])
     out["stable"] = stable
+    if snaps:
+        ns = min(SNAP_SOLVES, B)
+        H, n, m = p["H"], res[0]["node_x"].shape[1], res[0]["node_u"].shape[1]
+        sx = np.full((ns, len(SNAP_ITERS), H + 1, n), np.nan)
+        su = np.full((ns, len(SNAP_ITERS), H, m), np.nan)
+        sc = np.full((ns, len(SNAP_ITERS)), np.nan)
+        for i in range(ns):
+            for j, it in enumerate(SNAP_ITERS):
+                if it in res[i]["snaps"]:
+                    sx[i, j], su[i, j], sc[i, j] = res[i]["snaps"][it]
+        out.update(snap_iters=np.array(SNAP_ITERS), snap_x=sx, snap_u=su, snap_cost=sc)
     out["x0_raised"] = x0s_all[raised]          # start states on which the reference raised LinAlgError
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
@@ -499,12 +539,18 @@ def main():
         x0 = np.concatenate([np.zeros((1, 4)), lat_x0(a.lat - 1, 0)])
         run_set("lat_legacy", lat_problem(50), x0, a.jobs)
     if want("kin_legacy"):
-        run_set("kin_legacy", full_problem("kin", 50), full_x0(a.kin, 1), a.jobs)
+        run_set("kin_legacy", full_problem("kin", 20), full_x0(a.kin, 1), a.jobs)
+    if want("kin_legacy_h50"):
+        p = full_problem("kin", 50)
+        p.update(R=np.eye(2) * 100.0)
+        run_set("kin_legacy_h50", p, full_x0(24, 1), a.jobs)
     if want("dyn_legacy"):
         run_set("dyn_legacy", full_problem("dyn", 100), full_x0(a.full, 2), a.jobs)
     if want("fast_box"):
         x0 = full_x0(a.full, 4); x0[0] = [0, 0, 0, 0, 10, 0]
-        run_set("fast_box", fast_box_problem(50), x0, a.jobs)
+        run_set("fast_box", fast_box_problem(50), x0, a.jobs, snaps=True)
+    if want("fast_box_linear_h100"):
+        run_set("fast_box_linear_h100", fast_box_linear_problem(100), full_x0(32, 2), a.jobs, snaps=True)
     if want("fast_linear"):
         run_set("fast_linear", fast_linear_problem(50), full_x0(a.full, 5), a.jobs)
     if want("fast_equality"):
