@@ -38,6 +38,7 @@
 // the array aliasing of forward() after its first rejected step, :137-138) and
 // cilqr/fast_ilqr.py:10-176 (FAST).
 #pragma once
+#include <cstddef>
 #include "models.hpp"
 
 namespace alilqr {
@@ -46,7 +47,7 @@ namespace alilqr {
 // sets bit `code` of a word in the scratch's counter block (read back by alilqr_debug_read) and the offset is
 // clamped, so a bad index is reported instead of faulting the GPU.
 #ifdef ALILQR_DEBUG_BOUNDS
-#define ALILQR_CHK(cond, code) ((cond) ? true : (atomicOr(a.counter + 8, 1u << (code)), false))
+#define ALILQR_CHK(cond, code) ((cond) ? true : (atomicOr(ALILQR_COLD(counter) + 8, 1u << (code)), false))
 #else
 #define ALILQR_CHK(cond, code) (true)
 #endif
@@ -54,7 +55,7 @@ namespace alilqr {
 #ifdef ALILQR_PROF
 #define PROF_DECL unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PROF_MARK(i) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += t_ - prof_t0; prof_t0 = t_; }
-#define PROF_FLUSH(a) if (lane == 0 && (a).prof) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd((a).prof + i_, prof_acc[i_]); atomicAdd((a).prof + 8, 1ull); }
+#define PROF_FLUSH(a) { unsigned long long* const pr_ = ALILQR_COLD(prof); if (lane == 0 && pr_) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(pr_ + i_, prof_acc[i_]); atomicAdd(pr_ + 8, 1ull); } }
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
@@ -70,6 +71,52 @@ __device__ __forceinline__ ctab as_ctab(const double* p) {
   return (ctab)p;
 #pragma clang diagnostic pop
 }
+
+// Cold kernel arguments.  solve_kernel takes one argument block (KArgs) of ~60 scalar registers' worth of pointers and
+// constants.  A field that is named as a.field is loaded once at kernel entry and then held for the whole solve - or,
+// with every scalar register taken, parked in lanes of a vector register and fetched back (v_readlane) inside the
+// step loops.  Most fields are needed once per problem or once per inner iteration (outputs, optional inputs, the
+// solver constants of the bookkeeping phase): ALILQR_COLD(field) reads such a field from the argument block in the
+// constant (kernarg) segment at the place of use - one scalar load - and nothing stays live in between.  The empty asm
+// makes the address opaque, so the load is not hoisted back to the kernel entry.  The argument block is the kernel's
+// only parameter and therefore starts at offset 0 of the segment.  (Host builds of this source read a.field.)
+template <class T>
+__device__ __forceinline__ T cold_arg(size_t offset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const char __attribute__((address_space(4)))* base =
+      (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(base));
+  return *(const T __attribute__((address_space(4)))*)(base + offset);
+#else
+  (void)offset;
+  return T{};
+#endif
+}
+// ALILQR_COLD: fields needed once per problem (outputs, optional inputs); ALILQR_COLD2: once per inner iteration (the
+// constants of the bookkeeping phase, the trace); ALILQR_COLD3: the rectangle lists of the row activation.
+#ifndef ALILQR_COLD_LEVEL
+#define ALILQR_COLD_LEVEL 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ALILQR_COLD_(f) (alilqr::cold_arg<decltype(alilqr::KArgs::f)>(offsetof(alilqr::KArgs, f)))
+#else
+#define ALILQR_COLD_(f) (a.f)
+#endif
+#if ALILQR_COLD_LEVEL >= 1
+#define ALILQR_COLD(f) ALILQR_COLD_(f)
+#else
+#define ALILQR_COLD(f) (a.f)
+#endif
+#if ALILQR_COLD_LEVEL >= 2
+#define ALILQR_COLD2(f) ALILQR_COLD_(f)
+#else
+#define ALILQR_COLD2(f) (a.f)
+#endif
+#if ALILQR_COLD_LEVEL >= 3
+#define ALILQR_COLD3(f) ALILQR_COLD_(f)
+#else
+#define ALILQR_COLD3(f) (a.f)
+#endif
 
 #ifdef ALILQR_LIT_LAT
 __constant__ const double kLitQ[16] = {1e-3, 0, 0, 0, 0, 1e-1, 0, 0, 0, 0, 1e1, 0, 0, 0, 0, 1e-9};
@@ -1268,7 +1315,10 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
 
   // number of line-search trials the reference can make: alpha = 1, 1/2, ... while alpha > alpha_min
   int ntrials = 0;
-  for (double al = 1.0; al > a.prm.alpha_min && ntrials < 64; al = al / 2.0) ++ntrials;
+  {
+    const double alpha_min = ALILQR_COLD(prm.alpha_min);
+    for (double al = 1.0; al > alpha_min && ntrials < 64; al = al / 2.0) ++ntrials;
+  }
   if (NEWAL) ntrials = 10;                             // new_al_ilqr.h:1045
 
   // ---- per-group state (identical in every lane of a group) ----
@@ -1292,7 +1342,6 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   bool keep_old = false, gate_skip = false, have = false;
   int win_trial = -1, win_lane = -1, r0 = 0, replay_kind = 0;
   int nt0 = 0;                // roll-out count when the running line search started (trace output)
-  int stop_k = 0;             // the problem ends after this inner iteration (alilqr_extras::stop_after), 0: never
   bool xo_pend = false;       // the (x, u) pair to return is a trajectory in the slots, not yet copied to x_out / u_out
   int xo_par = 0, xo_slot = 0;
   // LEGACY: bit t set = some multiplier of node t is not zero (nodes 0 .. 127; longer horizons load them always).
@@ -1375,13 +1424,20 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
     // ================= problem switch: pull + initial guess =================
     if (p < 0 && !drained) {
       int np = 0;
-      if (gl == 0) np = (int)(atomicAdd(a.counter, 1u) - a.counter_base);
+      if (gl == 0) np = (int)(atomicAdd(ALILQR_COLD(counter), 1u) - ALILQR_COLD(counter_base));
       np = gbcast_i<G>(np, 0);
-      if (np >= a.B || !ALILQR_CHK(np >= 0, 11)) {
+      if (np >= ALILQR_COLD(B) || !ALILQR_CHK(np >= 0, 11)) {
         drained = true;
       } else {
         p = np;
         const double* goals = a.goals + ((a.goal_batch > 1) ? (size_t)p * XS : 0);
+        // outputs / optional inputs of the initial guess, read from the argument block here (see ALILQR_COLD)
+        double* const o_xi = ALILQR_COLD(x_init);
+        double* const o_ui = ALILQR_COLD(u_init);
+        double* const o_xo = ALILQR_COLD(x_out);
+        double* const o_uo = ALILQR_COLD(u_out);
+        const double* const i_uoff = ALILQR_COLD(u_off);
+        const double init_r = ALILQR_COLD(prm.init_r);
         // zero multipliers into the records, lanes in parallel
         lmask0 = 0ull; lmask1 = 0ull;
         for (int t = gl; t <= H; t += G) {
@@ -1390,7 +1446,8 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           if (RECT) {
             for (int i = 0; i < 2 * C; ++i) r[(size_t)(RL::rl + C + i) * ES] = 0.0;
             // the caller's per-node start rows are device data the host cannot check: keep them inside the table
-            int fr = a.first_rows ? a.first_rows[t] : a.first_row;
+            const int32_t* const frs = ALILQR_COLD(first_rows);
+            int fr = frs ? frs[t] : ALILQR_COLD(first_row);
             fr = fr < 0 ? 0 : (fr >= C ? C - 1 : fr);
             r[(size_t)(RL::rl + 3 * C) * ES] = (double)fr;
           }
@@ -1426,7 +1483,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
             }
 #pragma unroll
             for (int b = 0; b < M; ++b) {
-              double acc = (r == b) ? a.prm.init_r : 0.0;
+              double acc = (r == b) ? init_r : 0.0;
 #pragma unroll
               for (int k = 0; k < N; ++k)
                 if (b_nz<MD>(k, r)) acc = fma(Bm[k][r], Tm[k][b], acc);
@@ -1473,12 +1530,12 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           const int cs = 0;
           double x[N];
 #pragma unroll
-          for (int i = 0; i < N; ++i) x[i] = a.x0[(size_t)p * N + i];
+          for (int i = 0; i < N; ++i) x[i] = ALILQR_COLD(x0)[(size_t)p * N + i];
           if (gl == 0) {
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-              if (a.x_init) a.x_init[(size_t)p * XS + i] = x[i];
-              a.x_out[(size_t)p * XS + i] = x[i];
+              if (o_xi) o_xi[(size_t)p * XS + i] = x[i];
+              o_xo[(size_t)p * XS + i] = x[i];
               // node 0 keeps the wrapped start state from its first cost() call on (lat_bicycle_node.py:27-30,94)
               *trj_at(0, i, cs) = (!NEWAL && MD::WRAPS && (i == 2 || i == 3)) ? wrap_py(x[i]) : x[i];
             }
@@ -1491,7 +1548,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
               double acc = 0.0;
 #pragma unroll
               for (int i = 0; i < N; ++i) acc += (-rt[(size_t)(RL::rK + r * N + i) * ES]) * (x[i] - goals[(size_t)t * N + i]);
-              if (a.u_off) acc = acc + a.u_off[(size_t)p * US + t * M + r];
+              if (i_uoff) acc = acc + i_uoff[(size_t)p * US + t * M + r];
               u[r] = acc;
             }
             MD::template step<false>(mc, x, u, xn);
@@ -1499,14 +1556,14 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
 #pragma unroll
               for (int r = 0; r < M; ++r) {
                 *trj_at(0, XS + t * M + r, cs) = u[r];
-                if (a.u_init) a.u_init[(size_t)p * US + t * M + r] = u[r];
-                a.u_out[(size_t)p * US + t * M + r] = u[r];
+                if (o_ui) o_ui[(size_t)p * US + t * M + r] = u[r];
+                o_uo[(size_t)p * US + t * M + r] = u[r];
               }
 #pragma unroll
               for (int i = 0; i < N; ++i) {
                 *trj_at(0, (t + 1) * N + i, cs) = xn[i];
-                if (a.x_init) a.x_init[(size_t)p * XS + (t + 1) * N + i] = xn[i];
-                a.x_out[(size_t)p * XS + (t + 1) * N + i] = xn[i];
+                if (o_xi) o_xi[(size_t)p * XS + (t + 1) * N + i] = xn[i];
+                o_xo[(size_t)p * XS + (t + 1) * N + i] = xn[i];
               }
             }
 #pragma unroll
@@ -1514,8 +1571,10 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           }
         }
         mu = 1.0;
-        mu_s = (NEWAL && a.mu_s_in) ? a.mu_s_in[p] : 1.0;
-        stop_k = a.stop_after ? a.stop_after[p] : 0;
+        {
+          const double* const msi = NEWAL ? ALILQR_COLD(mu_s_in) : nullptr;
+          mu_s = msi ? msi[p] : 1.0;
+        }
         xo_pend = false;
         cur_slot = 0; cur_par = 0;
         outer = 0; inner = 0; n_inner = 0; n_trials = 0;
@@ -1541,8 +1600,8 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           const double px = *trj_at(cur_par, t * N + 0, cur_slot), py = *trj_at(cur_par, t * N + 1, cur_slot);
           ctab Cv = tabC(t) + C * (N + M);
           for (int side = 0; side < 2; ++side) {
-            ctab obs = as_ctab(side == 0 ? a.left_obs : a.right_obs);
-            const int cnt = side == 0 ? a.n_left : a.n_right;
+            ctab obs = as_ctab(side == 0 ? ALILQR_COLD3(left_obs) : ALILQR_COLD3(right_obs));
+            const int cnt = side == 0 ? ALILQR_COLD3(n_left) : ALILQR_COLD3(n_right);
             for (int k = 0; k < cnt; ++k) {
               ctab vx = obs + (size_t)k * 8, vy = vx + 4;
               bool inside = true;
@@ -1750,7 +1809,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
       keep_old = false;                          // NEW_AL: the trial costs were not finite, the trajectory stays
       win_trial = -1; win_lane = -1;
       J_last = 0.0;
-      gate_skip = NEWAL && (fabs(dv_lin) < a.prm.dv_gate);      // new_al_ilqr.h:1039
+      gate_skip = NEWAL && (fabs(dv_lin) < ALILQR_COLD2(prm.dv_gate));      // new_al_ilqr.h:1039
       stage = gate_skip ? ST_DONE : ST_TRIALS;
       r0 = 0;                                    // first trial of the current round, or first ladder column
       replay_kind = 0; replay_alpha = 0.0; bestJ = 0.0; bestA = 0.0; have = false;
@@ -2168,13 +2227,20 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
 
       // ================= P4: inner / outer bookkeeping (ilqr.py:158-174) =================
       ++n_inner; ++inner;
-      if (gl == 0 && n_inner <= a.trace_cap) {
-        if (a.trace_cost) a.trace_cost[(size_t)p * a.trace_cap + (n_inner - 1)] = new_cost;
-        if (a.trace_trials) a.trace_trials[(size_t)p * a.trace_cap + (n_inner - 1)] = n_trials - nt0;
+      {
+        const int trace_cap = ALILQR_COLD2(trace_cap);
+        if (gl == 0 && n_inner <= trace_cap) {
+          double* const tc = ALILQR_COLD2(trace_cost);
+          int32_t* const tt = ALILQR_COLD2(trace_trials);
+          if (tc) tc[(size_t)p * trace_cap + (n_inner - 1)] = new_cost;
+          if (tt) tt[(size_t)p * trace_cap + (n_inner - 1)] = n_trials - nt0;
+        }
       }
       // inner stop rule: |dJ| < tol (ilqr.py:162) ; 0 <= J_old - J_new < tol (new_al_ilqr.h:1118)
-      const bool brk = NEWAL ? ((old_cost - new_cost < a.prm.inner_tol) && (old_cost - new_cost >= 0))
-                             : (fabs(new_cost - old_cost) < a.prm.inner_tol);
+      const double inner_tol = ALILQR_COLD2(prm.inner_tol);
+      const int max_inner = ALILQR_COLD2(prm.max_inner);
+      const bool brk = NEWAL ? ((old_cost - new_cost < inner_tol) && (old_cost - new_cost >= 0))
+                             : (fabs(new_cost - old_cost) < inner_tol);
       if (!brk && !keep_old) {
         if (!NEWAL) {
           // x, u = new_x, new_u : the pair optimize() will return (the C++ generation returns its live arrays).
@@ -2185,20 +2251,28 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
       }
       bool finished = false;
       unsigned flags = 0;
-      const bool stop_now = stop_k > 0 && n_inner >= stop_k;
-      if (brk || inner >= a.prm.max_inner || stop_now) {
+      // diagnostic stop (alilqr_extras::stop_after): the pointer is read from the argument block here, once per inner
+      // iteration, so that nothing of it stays live in the step loops
+      bool stop_now = false;
+      {
+        const int32_t* const sa = ALILQR_COLD_(stop_after);
+        if (sa) { const int stop_k = sa[p]; stop_now = stop_k > 0 && n_inner >= stop_k; }
+      }
+      if (brk || inner >= max_inner || stop_now) {
         if (!NEWAL && xo_pend) {
           // The pair to return is the trajectory of the last iteration that did not end the inner loop.  It sits in
           // the parity this iteration's candidates were NOT written to (or is the one just accepted), so it is
           // still whole; the next outer iteration's first line search will overwrite it.
-          for (int e = gl; e < XS; e += G) a.x_out[(size_t)p * XS + e] = *trj_at(xo_par, e, xo_slot);
-          for (int e = gl; e < US; e += G) a.u_out[(size_t)p * US + e] = *trj_at(xo_par, XS + e, xo_slot);
+          double* const o_xo = ALILQR_COLD(x_out);
+          double* const o_uo = ALILQR_COLD(u_out);
+          for (int e = gl; e < XS; e += G) o_xo[(size_t)p * XS + e] = *trj_at(xo_par, e, xo_slot);
+          for (int e = gl; e < US; e += G) o_uo[(size_t)p * US + e] = *trj_at(xo_par, XS + e, xo_slot);
           xo_pend = false;
         }
       }
       if (stop_now) {
         finished = true; flags = ALILQR_FLAG_STOPPED;
-      } else if (brk || inner >= a.prm.max_inner) {
+      } else if (brk || inner >= max_inner) {
         // constraint violation of the node trajectory, nodes in parallel, combined in node order
         double vtot = OPS::violation_init();
         for (int t0 = 0; t0 <= H; t0 += G) {
@@ -2220,11 +2294,12 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         }
         viol = vtot;
         ++outer;
-        if (viol < a.prm.viol_stop) {
+        const double viol_stop = ALILQR_COLD2(prm.viol_stop), viol_lambda = ALILQR_COLD2(prm.viol_lambda);
+        if (viol < viol_stop) {
           finished = true; flags = ALILQR_FLAG_VIOL_OK;
         } else {
           // multiplier update vs penalty increase: ilqr.py:169-174 ; new_al_ilqr.h:1198-1211
-          if (NEWAL ? !(viol > a.prm.viol_lambda) : (viol >= a.prm.viol_stop && viol < a.prm.viol_lambda)) {
+          if (NEWAL ? !(viol > viol_lambda) : (viol >= viol_stop && viol < viol_lambda)) {
             lmask0 = 0ull; lmask1 = 0ull;
             for (int t0 = 0; t0 <= H; t0 += G) {
               const int t = t0 + gl;
@@ -2248,40 +2323,51 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
             }
             __threadfence_block();
           } else {
-            if constexpr (NEWAL) { mu_s = mu_s * a.prm.mu_gain; mu = mu_s; }   // UpdateMu, new_al_ilqr.h:1125-1130
-            else mu = mu * a.prm.mu_gain;
+            const double mu_gain = ALILQR_COLD2(prm.mu_gain);
+            if constexpr (NEWAL) { mu_s = mu_s * mu_gain; mu = mu_s; }   // UpdateMu, new_al_ilqr.h:1125-1130
+            else mu = mu * mu_gain;
           }
-          if (outer >= a.prm.max_outer) { finished = true; flags = ALILQR_FLAG_OUTER_CAP; }
+          if (outer >= ALILQR_COLD2(prm.max_outer)) { finished = true; flags = ALILQR_FLAG_OUTER_CAP; }
           else outer_start = true;
         }
       }
       if (finished) {
         double fc = total_cost();
         if (NEWAL) {
-          for (int e = gl; e < XS; e += G) a.x_out[(size_t)p * XS + e] = *trj_at(cur_par, e, cur_slot);
-          for (int e = gl; e < US; e += G) a.u_out[(size_t)p * US + e] = *trj_at(cur_par, XS + e, cur_slot);
+          double* const o_xo = ALILQR_COLD(x_out);
+          double* const o_uo = ALILQR_COLD(u_out);
+          for (int e = gl; e < XS; e += G) o_xo[(size_t)p * XS + e] = *trj_at(cur_par, e, cur_slot);
+          for (int e = gl; e < US; e += G) o_uo[(size_t)p * US + e] = *trj_at(cur_par, XS + e, cur_slot);
         }
-        if (a.node_x) for (int e = gl; e < XS; e += G) a.node_x[(size_t)p * XS + e] = *trj_at(cur_par, e, cur_slot);
-        if (a.node_u) for (int e = gl; e < US; e += G) a.node_u[(size_t)p * US + e] = *trj_at(cur_par, XS + e, cur_slot);
-        if (a.lam)
+        double* const o_nx = ALILQR_COLD(node_x);
+        double* const o_nu = ALILQR_COLD(node_u);
+        double* const o_lam = ALILQR_COLD(lam);
+        if (o_nx) for (int e = gl; e < XS; e += G) o_nx[(size_t)p * XS + e] = *trj_at(cur_par, e, cur_slot);
+        if (o_nu) for (int e = gl; e < US; e += G) o_nu[(size_t)p * US + e] = *trj_at(cur_par, XS + e, cur_slot);
+        if (o_lam)
           for (int e = gl; e < (H + 1) * C; e += G)
-            a.lam[(size_t)p * (H + 1) * C + e] = rec(e / C)[(size_t)(RL::rl + e % C) * ES];
+            o_lam[(size_t)p * (H + 1) * C + e] = rec(e / C)[(size_t)(RL::rl + e % C) * ES];
         if constexpr (RECT) {
-          if (a.overlay_out)
+          double* const o_ov = ALILQR_COLD(overlay_out);
+          if (o_ov)
             for (int e = gl; e < (H + 1) * (2 * C + 1); e += G)
-              a.overlay_out[(size_t)p * (H + 1) * (2 * C + 1) + e] = rec(e / (2 * C + 1))[(size_t)(RL::rl + C + e % (2 * C + 1)) * ES];
+              o_ov[(size_t)p * (H + 1) * (2 * C + 1) + e] = rec(e / (2 * C + 1))[(size_t)(RL::rl + C + e % (2 * C + 1)) * ES];
         }
         if (gl == 0) {
-          if (NEWAL && a.mu_s_out) a.mu_s_out[p] = mu_s;
-          a.cost[p] = fc;
-          if (a.viol) a.viol[p] = viol;
-          if (a.mu) a.mu[p] = mu;
-          if (a.status) {
+          double* const o_ms = NEWAL ? ALILQR_COLD(mu_s_out) : nullptr;
+          double* const o_viol = ALILQR_COLD(viol);
+          double* const o_mu = ALILQR_COLD(mu);
+          int32_t* const o_st = ALILQR_COLD(status);
+          if (o_ms) o_ms[p] = mu_s;
+          ALILQR_COLD(cost)[p] = fc;
+          if (o_viol) o_viol[p] = viol;
+          if (o_mu) o_mu[p] = mu;
+          if (o_st) {
             if (!(fc - fc == 0.0)) flags |= ALILQR_FLAG_NONFINITE;
-            a.status[(size_t)p * ALILQR_STATUS_WORDS + 0] = n_inner;
-            a.status[(size_t)p * ALILQR_STATUS_WORDS + 1] = outer;
-            a.status[(size_t)p * ALILQR_STATUS_WORDS + 2] = (int32_t)flags;
-            a.status[(size_t)p * ALILQR_STATUS_WORDS + 3] = n_trials;
+            o_st[(size_t)p * ALILQR_STATUS_WORDS + 0] = n_inner;
+            o_st[(size_t)p * ALILQR_STATUS_WORDS + 1] = outer;
+            o_st[(size_t)p * ALILQR_STATUS_WORDS + 2] = (int32_t)flags;
+            o_st[(size_t)p * ALILQR_STATUS_WORDS + 3] = n_trials;
           }
         }
         p = -1;

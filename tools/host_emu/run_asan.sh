@@ -14,8 +14,8 @@ g++ -std=c++17 -O1 -g -fsanitize=$SAN -fno-sanitize-recover=all -fno-omit-frame-
     -x c++ tools/host_emu/driver.cpp -o "$OUT/driver" -lpthread
 for n in new_box new_box_active new_lat kin_rect lat_rect circle6 lat_circle fast_box; do
   python3 tools/host_emu/dump_problem.py $n $B "$OUT/$n.bin"
-  for L in 1 4; do
+  for L in ${LANES:-1 4}; do
     ALILQR_LANES=$L "$OUT/driver" "$OUT/$n.bin" "$OUT/${n}_$L.out" > "$OUT/${n}_$L.log" 2>&1 || { echo "$n lanes $L: FAILED"; tail -20 "$OUT/${n}_$L.log"; exit 1; }
   done
-  cmp "$OUT/${n}_1.out" "$OUT/${n}_4.out" && echo "$n: clean under -fsanitize=$SAN, 1 and 4 lanes give identical bytes"
+  first=""; for L in ${LANES:-1 4}; do [ -z "$first" ] && first=$L; cmp "$OUT/${n}_${first}.out" "$OUT/${n}_$L.out"; done && echo "$n: clean under -fsanitize=$SAN, lanes ${LANES:-1 4} give identical bytes"
 done
