@@ -75,7 +75,6 @@ constexpr size_t kStaticScratchBytes = (size_t)ALILQR_STATIC_SCRATCH_BYTES;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 struct StaticScratch {
   void* ptr = nullptr;            // device address of `scratch` on this device
-  bool zeroed = false;            // its counter block has been cleared once
   unsigned counter_next = 0;
 };
 StaticScratch g_static[kMaxDev];
@@ -564,11 +563,10 @@ static int32_t solve_impl(const alilqr_problem* p,
     StaticScratch* ss = nullptr;
     rc = static_scratch(dev, &ss);
     if (rc != ALILQR_OK) return rc;
-    if (!ss->zeroed) {
-      HIP_TRY(hipMemsetAsync(ss->ptr, 0, 256, st));          // counter block, once per device
-      ss->zeroed = true;
-      ss->counter_next = 0;
-    }
+    // The counter block is cleared in front of every solve (a memset node when the stream is being captured), and the
+    // solve counts from zero: a captured launch carries nothing of the host's state and can be replayed.
+    HIP_TRY(hipMemsetAsync(ss->ptr, 0, 256, st));
+    ss->counter_next = 0;
     base = (char*)ss->ptr;
     counter_next = &ss->counter_next;
     g_last_ws[dev] = ss->ptr;

@@ -337,11 +337,15 @@ int32_t alilqr_release(void);
  * no hipMalloc / hipFree.  The solve keeps as many problems resident as fit into that array (the others are
  * pulled as resident ones finish), so any batch size is accepted; ALILQR_E_NOMEM is returned only when the scratch
  * of a single wave (a very long horizon) exceeds the array.  All calls on one GPU share the array: calls that
- * overlap on one GPU (different streams, or threads) race - enqueue them on one stream.  The first call on a
- * device looks the array's address up and clears its counter block (one hipMemsetAsync): make that call outside
- * graph capture.  A captured launch cannot be replayed (the kernel arguments carry the counter position).
+ * overlap on one GPU (different streams, or threads) race - enqueue them on one stream.  Every call enqueues one
+ * 256-byte hipMemsetAsync (the problem counter) in front of the kernel(s).  The first call on a device looks the
+ * array's address up (hipGetSymbolAddress): make that call outside graph capture.  Later calls may be captured into a
+ * HIP graph, and the graph may be replayed: the enqueued work carries no state of the host.
+ * The array's size is fixed when the library is built (-DALILQR_STATIC_SCRATCH_BYTES=<bytes>, default 128 MiB).
  */
+#ifndef ALILQR_STATIC_SCRATCH_BYTES
 #define ALILQR_STATIC_SCRATCH_BYTES (128u << 20)
+#endif
 int32_t alilqr_solve_batch_noalloc(const alilqr_problem* p,
                                    const double* x0, const double* goals,
                                    const double* Q, const double* R, const double* cons,

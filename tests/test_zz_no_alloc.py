@@ -1,6 +1,8 @@
 """The entry point that allocates nothing (alilqr_solve_batch_noalloc) against alilqr_solve_batch, through the C ABI:
 bit-identical outputs on two calls in a row, the second on a smaller batch (the static scratch keeps the first
-call's contents), and on a batch whose scratch exceeds the static array (fewer resident groups, same bits)."""
+call's contents), and on a batch whose scratch exceeds the static array (fewer resident groups, same bits).  Also that
+the call really allocates nothing: the device's free memory does not move, and the call can be captured into a HIP
+graph in the capture mode that refuses allocations, and replayed."""
 import ctypes as C
 
 import numpy as np
@@ -64,3 +66,44 @@ def test_noalloc_rejects_a_horizon_whose_single_wave_does_not_fit():
     s = batch.BatchSolver(desc, x0, goals, Q, R, cons)
     with pytest.raises(RuntimeError, match="static scratch"):
         s.run(noalloc=True)
+
+
+def test_noalloc_leaves_the_free_device_memory_where_it_was():
+    """hipMemGetInfo before and after: the call takes no device memory (the pooled entry point, on a size it has not
+    seen, does)."""
+    import torch
+    prob = problems.lat_legacy(700, 50, seed=44)
+    s = batch.BatchSolver(*prob, extras=True)          # inputs and outputs are allocated here, not by run()
+    s.run(noalloc=True)                                # first call on the device: address look-up
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        s.run(noalloc=True)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    capi.release()                                     # the pooled entry point has to allocate its scratch again
+    free1 = torch.cuda.mem_get_info()[0]
+    s.run(noalloc=False)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] < free1        # the measure does see an allocation made by the library
+
+
+def test_noalloc_call_is_captured_into_a_graph_and_replayed():
+    """Stream capture in the mode that makes every allocating runtime call fail: the call is captured (one memset node,
+    the row-analysis and solve kernels) and each replay of the graph solves the batch again, same bits."""
+    import torch
+    for prob in (problems.lat_legacy(130, 50, seed=45), problems.fast_box(24)):
+        ref = _run(batch.BatchSolver(*prob, extras=True), False)
+        s = batch.BatchSolver(*prob, extras=True)
+        s.run(noalloc=True)                            # outside capture: the first call looks the scratch address up
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=torch.cuda.Stream(), capture_error_mode="global"):
+            s.run(noalloc=True)                        # enqueued on the capturing stream (the current one in here)
+        for _ in range(2):
+            for k in KEYS:
+                s.out[k].zero_()
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            _same({k: s.out[k].cpu().numpy() for k in KEYS}, ref, "graph replay")
