@@ -7,11 +7,17 @@ with seed = rank) per GPU, weak scaling.  Inputs are resident in HBM before the 
 exchange data, so the ranks shard the batch with no collective inside the solve; one gather of the final cost
 vectors over RCCL at the end of the K steps is the only exchange.
 
-Consecutive steps are independent batches.  They are enqueued on --pipeline (default 12, at most 16) HIP streams in turn, each
-with its own output buffers and its own scratch inside the library, so the next batches fill the SIMDs that the
-tail of a batch leaves idle (a batch ends when its longest solve ends).  The process asks the HIP runtime for 16
-hardware queues (--hw-queues): with the default 4, streams share queues and their kernels run one after the other.
-All K steps complete inside the timed region; --pipeline 1 gives the one-launch-at-a-time number.
+Consecutive steps are independent batches (each with start states and output buffers of its own).  A batch ends
+when its longest solve ends, so batches solved one call at a time leave the SIMDs idle during every tail.  Two ways
+to keep the machine full:
+  --group G (default 10; configurations 2, 4a, 4b)  G consecutive steps are handed to the library in ONE call
+      (alilqr_solve_batches): it solves them as one batch, the resident lane groups pull problems of all G batches
+      from one queue.  --pipeline calls (default 2) are in flight on as many streams, so the tail of one call
+      overlaps with the next.  Needs no more than HIP's default hardware queues.
+  --group 1  one alilqr_solve_batch per step on --pipeline (default 12, at most 16) streams in turn; the process asks
+      the HIP runtime for 16 hardware queues (--hw-queues): with the default 4, streams share queues and their
+      kernels run one after the other.  (Configurations 3 and 5 take optional inputs and always run this way.)
+All K steps complete inside the timed region; --group 1 --pipeline 1 gives the one-launch-at-a-time number.
 
   python bench.py --gpus N --steps K --warmup W [--config 2|3|4a|4b|5] [--scaling weak|strong] [--batch B]
 
@@ -136,10 +142,14 @@ def main():
     ap.add_argument("--max-waves", type=int, default=0,
                     help="resident waves per launch (0 = the library's choice); with fewer waves than problem pairs a lane "
                          "group pulls its next problem when it finishes one")
-    ap.add_argument("--pipeline", type=int, default=12, help="batches in flight (HIP streams used in turn)")
+    ap.add_argument("--group", type=int, default=10,
+                    help="steps (batches) per library call: 1 = one alilqr_solve_batch per step; > 1 = alilqr_solve_batches")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="calls in flight (HIP streams used in turn); 0 = 2 with --group > 1, 12 with --group 1")
     ap.add_argument("--hw-queues", type=int, default=16,
                     help="GPU_MAX_HW_QUEUES for this process (HIP's default of 4 makes streams share a hardware "
                          "queue, and kernels on one queue run one after the other); 0 leaves the environment's value")
+    ap.add_argument("--no-order-hint", action="store_true", help="skip the second timed region (pull-order hint)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: take the multi-rank path (process group, gather, barriers) with one rank too")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -196,9 +206,20 @@ def main():
     if B < 1:
         raise SystemExit("this rank has no problems: use a larger --batch")
 
-    depth = max(1, min(16, args.pipeline))
-    solvers = [batch.BatchSolver(*prob, extras=False, device=dev, **kw) for _ in range(depth)]
+    group = max(1, args.group)
+    if kw or args.config in ("3", "5"):
+        group = 1                                   # optional inputs (rectangles, control offsets): one call per step
+    depth = max(1, min(16, args.pipeline or (2 if group > 1 else 12)))
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+    if group > 1:
+        # every batch of a call has start states of its own (seeded by rank and position in the call)
+        x0s = [prob[1]] + [make_workload(args.config, B, 1000 * (rank + 1) + j)[0][1] for j in range(1, group)]
+        if scaling == "strong":
+            x0s = [prob[1]] * group                 # the sharded global batch, repeated
+        solvers = [batch.MultiBatchSolver(desc, x0s, *prob[2:6], extras=False, device=dev) for _ in range(depth)]
+    else:
+        solvers = [batch.BatchSolver(*prob, extras=False, device=dev, **kw) for _ in range(depth)]
+    single = solvers[0] if group == 1 else batch.BatchSolver(*prob, extras=False, device=dev, **kw)
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
     # The only exchange of the job: one gather (RCCL) of the cost vectors the solve streams hold when the K steps
     # are done, inside the timed region.  The solves themselves need no collective.
@@ -210,57 +231,110 @@ def main():
     final = torch.zeros((depth, maxB), dtype=torch.float64, device=gdev) if multi else None
     gathered = torch.empty((world, depth, maxB), dtype=torch.float64, device=gdev) if multi else None
 
+    def last_out(sv):
+        return sv.out[0] if group > 1 else sv.out
+
     def gather_costs():
         for i, sv in enumerate(solvers):
             torch.cuda.current_stream(dev).wait_stream(streams[i])
-            final[i, :B].copy_(sv.out["cost"])
+            final[i, :B].copy_(last_out(sv)["cost"])
         dist.all_gather_into_tensor(gathered.view(-1), final.view(-1))
 
-    # set-up, not a step: every stream's first solve allocates that stream's scratch inside the library
-    for sv, st in zip(solvers, streams):
-        with torch.cuda.stream(st):
-            sv.run(st.cuda_stream)
-    torch.cuda.synchronize(dev)
+    orders = {}          # (stream slot, batches in the call) -> pull order from the previous solve of those batches
 
-    def step(k, ev=None):
+    def call(k, n, ev=None, hinted=False):
+        """library call number k: n steps (batches) on stream k % depth"""
         i = k % depth
         with torch.cuda.stream(streams[i]):
             if ev is not None:
                 ev[0].record(streams[i])
-            out = solvers[i].run(streams[i].cuda_stream)
+            if group > 1:
+                solvers[i].run(streams[i].cuda_stream, n=n, order=orders.get((i, n)) if hinted else None)
+            else:
+                solvers[i].run(streams[i].cuda_stream)
             if ev is not None:
                 ev[1].record(streams[i])
-        return out
+        return solvers[i]
 
-    for k in range(args.warmup):
-        step(k)
+    def calls_of(steps):
+        """the steps of a region as library calls: (steps in the call) per call"""
+        return [min(group, steps - s) for s in range(0, steps, group)]
+
+    # set-up, not a step: every stream's first solve allocates that stream's scratch inside the library
+    for i in range(depth):
+        call(i, group)
+    torch.cuda.synchronize(dev)
+
+    for k, ns in enumerate(calls_of(args.warmup)):
+        call(k, ns)
     if multi:
         gather_costs()                      # also brings the communicator up before the timed region
     torch.cuda.synchronize(dev)
     if multi:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    out = None
-    for k in range(args.steps):
-        out = step(k, ev[k])
-    if multi:
-        gather_costs()
-    torch.cuda.synchronize(dev)
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    if multi:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    plan = calls_of(args.steps)
+
+    def timed_region(hinted):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in plan]
+        torch.cuda.synchronize(dev)
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        sv = None
+        for k, ns in enumerate(plan):
+            sv = call(k, ns, ev[k], hinted)
+        if multi:
+            gather_costs()
+        torch.cuda.synchronize(dev)
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if multi:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, ev, sv
+
+    dt, ev, sv = timed_region(False)
+    # Pull-order hint (group mode), reported next to the main number and never as `value`.  A planning loop solves,
+    # cycle after cycle, problems that differ little from the previous cycle's; the inner-iteration counts of the
+    # previous cycle predict this cycle's.  Emulated here: every call's batches are solved once OUTSIDE the timed
+    # region from start states moved by 1 % of their spread ("the previous cycle"), and the K steps are timed once more
+    # with every call pulling its problems longest-first by those counts (the order argument of alilqr_solve_batches).
+    hint = None
+    if group > 1 and not args.no_order_hint:
+        spread = np.array([0.0, 1.0, 0.2, 0.05]) if n == 4 else np.array([0.0, 1.0, 0.1, 0.0, 1.0, 0.0])
+        rng = np.random.default_rng(12345 + rank)
+        prev_x0s = [np.asarray(x) + 0.01 * spread * rng.standard_normal(np.asarray(x).shape) for x in x0s]
+        prev = batch.MultiBatchSolver(desc, prev_x0s, *prob[2:6], extras=False, device=dev)
+        prev.run()
+        torch.cuda.synchronize(dev)
+        for ns in set(plan):
+            od = prev.order_by_last_solve(ns)
+            for i in range(depth):
+                orders[(i, ns)] = od
+        prev_iters = torch.cat([o["status"][:, 0] for o in prev.out]).cpu().numpy()
+        del prev
+        dt_h, _, sv_h = timed_region(True)
+        now_iters = torch.cat([o["status"][:, 0] for o in sv_h.out]).cpu().numpy()
+        ra, rb = np.argsort(np.argsort(prev_iters)), np.argsort(np.argsort(now_iters))
+        hint = {"value": global_B * args.steps / dt_h, "ms_per_step": dt_h / args.steps * 1e3,
+                "source": "inner-iteration counts of the same batches solved, outside the timed region, from start states "
+                          "moved by 1 % of their spread (the previous cycle of a planning loop); longest first",
+                "rank_correlation_with_actual_counts": float(np.corrcoef(ra, rb)[0, 1])}
+    # per-problem status words of the last call's batches (the algorithmic operation count comes from them)
+    last_n = plan[-1]
+    outs = sv.out[:last_n] if group > 1 else [sv.out]
+    out = outs[0]
 
     # outside the timed region: the same launch alone on the device, for the record
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(streams[0]):
-        e0.record(streams[0]); solvers[0].run(streams[0].cuda_stream); e1.record(streams[0])
+        single.run(streams[0].cuda_stream)                     # set-up: scratch of this size
+        e0.record(streams[0]); single.run(streams[0].cuda_stream); e1.record(streams[0])
     torch.cuda.synchronize(dev)
     lone_ms = e0.elapsed_time(e1)
     # and a launch that leaves every wave a SIMD to itself (1024 problems = 512 waves on 1024 SIMDs): the latency of
@@ -275,12 +349,15 @@ def main():
     light_ms = e0.elapsed_time(e1)
     light_iters = int(lout["status"][:, 0].max().item())
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    status = out["status"].cpu().numpy()
-    cost = out["cost"].cpu().numpy()
-    flops = algorithmic_flops(status, H, n)
+    # a launch = one library call = `steps_per_launch` steps; duration of the last call's size class only
+    full = [i for i, n_ in enumerate(plan) if n_ == last_n]
+    kernel_ms = float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in full]))
+    status = np.concatenate([o["status"].cpu().numpy() for o in outs])
+    cost = np.concatenate([o["cost"].cpu().numpy() for o in outs])
+    flops = algorithmic_flops(status, H, n)                      # of one launch (last_n steps)
     tf = flops / (kernel_ms * 1e-3) / 1e12                       # per launch, as each launch experienced it
-    tf_job = flops * args.steps / dt / 1e12                      # all launches of the timed region over its wall time
+    tf_job = flops / last_n * args.steps / dt / 1e12             # all steps of the timed region over its wall time
+    single_status = single.out["status"].cpu().numpy()
     hit_cap = float(np.mean((status[:, 2] & capi.FLAG_OUTER_CAP) != 0))
     viol_ok = float(np.mean((status[:, 2] & capi.FLAG_VIOL_OK) != 0))
 
@@ -305,10 +382,13 @@ def main():
                                       else f"global batch {global_B} sharded over {world} GPU(s)"),
                        "config": args.config, "batch_per_gpu": B, "global_batch": global_B, "horizon": H,
                        "lanes_per_problem": args.lanes or "auto",
-                       "batches_in_flight": depth, "lone_launch_ms": lone_ms,
+                       "steps_per_call": group, "calls_in_flight": depth,
+                       "entry_point": "alilqr_solve_batches" if group > 1 else "alilqr_solve_batch",
+                       "with_order_hint": hint,
+                       "lone_launch_ms": lone_ms,
                        # latency of one iLQR iteration (linearise, backward sweep, line search) of one problem with the
                        # whole batch resident: a lone launch lasts as long as its longest solve
-                       "per_iter_latency_us": lone_ms * 1e3 / max(1, int(status[:, 0].max())),
+                       "per_iter_latency_us": lone_ms * 1e3 / max(1, int(single_status[:, 0].max())),
                        # the same with 1024 problems resident (one wave per SIMD at most)
                        "light_load": {"batch": light_B, "launch_ms": light_ms,
                                       "per_iter_latency_us": light_ms * 1e3 / max(1, light_iters)},
@@ -326,11 +406,12 @@ def main():
                          # kernel_ms is a launch as it experienced the machine: `launches_in_flight` launches share the GPU, so
                          # a launch lasts about that many times its share; achieved_job / frac_job are the algorithmic
                          # flops of all K launches over the wall time of the timed region
-                         "kernel": "alilqr::solve_kernel", "kernel_ms": kernel_ms, "launches_in_flight": depth,
+                         "kernel": "alilqr::solve_kernel", "kernel_ms": kernel_ms, "launches_in_flight": min(depth, len(plan)),
+                         "steps_per_launch": last_n,
                          "achieved_job": tf_job, "frac_job": tf_job / FP64_VALU_PEAK_TFLOPS,
                          "algorithmic_flops_per_launch": flops,
-                         "algorithmic_hbm_bytes_per_launch": algorithmic_bytes(desc),
-                         "hbm_GBs_algorithmic": algorithmic_bytes(desc) / (kernel_ms * 1e-3) / 1e9,
+                         "algorithmic_hbm_bytes_per_launch": algorithmic_bytes(desc) * last_n,
+                         "hbm_GBs_algorithmic": algorithmic_bytes(desc) * last_n / (kernel_ms * 1e-3) / 1e9,
                          "hbm_peak_GBs": HBM_PEAK_GBS, "kernel_source_id": kernel_source_id()},
         }
         if world == 1 and not args.no_cpu:

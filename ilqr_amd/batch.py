@@ -37,7 +37,7 @@ def _require_gpu(device):
 
 def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=True, u_offset=None,
                 left_obs=None, right_obs=None, first_row=0, trace=0, mu_solver=None, first_rows=None, overlay=False,
-                stop_after=None):
+                stop_after=None, order=None):
     """Solve ``desc.batch`` problems on the GPU.
 
     Inputs may be numpy arrays or torch tensors (moved to ``device`` as fp64):
@@ -102,6 +102,12 @@ def solve_batch(desc, x0, goals, Q, R, cons, extras=True, device="cuda:0", sync=
     if overlay:
         out["overlay"] = torch.zeros((B, H + 1, 2 * c + 1), **f64)
         ex.overlay_out = out["overlay"].data_ptr()
+    if order is not None:
+        od = torch.as_tensor(np.ascontiguousarray(order, dtype=np.int32), device=dev) if not isinstance(order, torch.Tensor) else order.to(device=dev, dtype=torch.int32)
+        if od.numel() != B:
+            raise ValueError("order must be a permutation of the batch")
+        keep.append(od)
+        ex.order = od.data_ptr()
     if stop_after is not None:
         sa = torch.as_tensor(np.ascontiguousarray(np.broadcast_to(np.asarray(stop_after, dtype=np.int32), (B,))), device=dev)
         keep.append(sa)
@@ -174,6 +180,67 @@ class BatchSolver:
                 rc = fn(C.byref(self.desc), *[_ptr(t) for t in self.inputs], *outs, C.c_void_p(stream_ptr))
         capi.check(rc, "alilqr_solve_batch_noalloc" if noalloc else "alilqr_solve_batch")
         return o
+
+
+class MultiBatchSolver:
+    """Several batches of one problem family, each with start states and outputs in buffers of its own, solved by ONE
+    call (``alilqr_solve_batches``): the library runs them as one batch, so stragglers of one batch overlap with the
+    work of the others.  ``desc.batch`` is the size of each batch; ``x0_list`` holds one [B, n] array per batch."""
+
+    def __init__(self, desc, x0_list, goals, Q, R, cons, extras=False, device="cuda:0"):
+        torch = _torch()
+        self.lib = capi.load_library()
+        self.dev = _require_gpu(device)
+        self.desc = desc
+        B, H, n, m = desc.batch, desc.horizon, desc.n, desc.m
+        self.x0 = [_dev_f64(a, self.dev) for a in x0_list]
+        if any(t.numel() != B * n for t in self.x0):
+            raise ValueError("every start-state array must hold batch*n values")
+        self.shared = [_dev_f64(a, self.dev) for a in (goals, Q, R, cons)]
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        self.out = []
+        for _ in self.x0:
+            o = dict(x=torch.empty((B, H + 1, n), **f64), u=torch.empty((B, H, m), **f64), cost=torch.empty((B,), **f64),
+                     status=torch.zeros((B, capi.STATUS_WORDS), dtype=torch.int32, device=self.dev))
+            if extras:
+                o.update(node_x=torch.empty((B, H + 1, n), **f64), node_u=torch.empty((B, H, m), **f64),
+                         viol=torch.empty((B,), **f64), mu=torch.empty((B,), **f64))
+            self.out.append(o)
+        n_b = len(self.x0)
+
+        def plist(key):
+            if key not in self.out[0]:
+                return None
+            return (C.c_void_p * n_b)(*[o[key].data_ptr() for o in self.out])
+        self._lists = [(C.c_void_p * n_b)(*[t.data_ptr() for t in self.x0])] + \
+            [plist(k) for k in ("x", "u", "node_x", "node_u", "cost", "viol", "mu", "status")]
+
+    def order_by_last_solve(self, n=None):
+        """Scheduling hint for the next ``run`` of the first ``n`` batches, from the status words the last run left:
+        the problems that needed most inner iterations first (int32 device permutation over the n * B problems)."""
+        torch = _torch()
+        n = len(self.x0) if n is None else int(n)
+        iters = torch.cat([o["status"][:, 0] for o in self.out[:n]])
+        return torch.argsort(iters, descending=True, stable=True).to(torch.int32)
+
+    def run(self, stream_ptr=None, n=None, order=None):
+        """Enqueue the solve of all batches (or of the first ``n``); returns the list of per-batch output dicts.
+        ``order``: optional int32 device permutation of the n * B problems (see ``order_by_last_solve``)."""
+        torch = _torch()
+        L = self._lists
+        n = len(self.x0) if n is None else int(n)
+        if not 0 <= n <= len(self.x0):
+            raise ValueError("n must be between 0 and the number of batches")
+        with torch.cuda.device(self.dev):
+            if stream_ptr is None:
+                stream_ptr = torch.cuda.current_stream(self.dev).cuda_stream
+            if order is not None and (order.dtype != torch.int32 or order.numel() != n * self.desc.batch):
+                raise ValueError("order must be an int32 permutation of the n * batch problems")
+            self._order = order                                    # kept alive until the next run
+            rc = self.lib.alilqr_solve_batches(C.byref(self.desc), n, L[0], *[_ptr(t) for t in self.shared],
+                                               *L[1:], _ptr(order), C.c_void_p(stream_ptr))
+        capi.check(rc, "alilqr_solve_batches")
+        return self.out
 
 
 def release():

@@ -48,7 +48,7 @@ class Extras(C.Structure):
                 ("n_left", C.c_int32), ("n_right", C.c_int32), ("first_row", C.c_int32), ("reserved", C.c_int32),
                 ("trace_cost", C.c_void_p), ("trace_trials", C.c_void_p), ("trace_cap", C.c_int32), ("reserved2", C.c_int32),
                 ("mu_solver_in", C.c_void_p), ("mu_solver_out", C.c_void_p), ("first_rows", C.c_void_p),
-                ("overlay_out", C.c_void_p), ("stop_after", C.c_void_p)]
+                ("overlay_out", C.c_void_p), ("stop_after", C.c_void_p), ("order", C.c_void_p)]
 
 
 def pack_rectangles(rects):
@@ -135,7 +135,7 @@ LIB_PATH = os.environ.get("ALILQR_LIB") or os.path.join(os.path.dirname(os.path.
 EXPORTS = ("alilqr_abi_version", "alilqr_last_error", "alilqr_device_count", "alilqr_default_params",
            "alilqr_workspace_bytes", "alilqr_solve_batch", "alilqr_solve_batch_multistart", "alilqr_solve_batch_ex",
            "alilqr_linearize_batch", "alilqr_node_aux_batch", "alilqr_constraints_batch",
-           "alilqr_release", "alilqr_solve_batch_noalloc", "alilqr_static_scratch_bytes", "alilqr_set_tuning")
+           "alilqr_solve_batches", "alilqr_release", "alilqr_solve_batch_noalloc", "alilqr_static_scratch_bytes", "alilqr_set_tuning")
 
 
 class LibraryMissing(RuntimeError):
@@ -176,6 +176,8 @@ def load_library():
     lib.alilqr_linearize_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17
     lib.alilqr_constraints_batch.restype = C.c_int32
     lib.alilqr_constraints_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 13
+    lib.alilqr_solve_batches.restype = C.c_int32
+    lib.alilqr_solve_batches.argtypes = [C.POINTER(Problem), C.c_int32] + [C.c_void_p] * 15
     lib.alilqr_release.restype = C.c_int32
     lib.alilqr_solve_batch_noalloc.restype = C.c_int32
     lib.alilqr_solve_batch_noalloc.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17

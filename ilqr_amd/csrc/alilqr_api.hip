@@ -153,6 +153,10 @@ int pick_group(const alilqr_problem* p) {
   // and their 6-state kernels carry twice the registers per lane
   const bool wide = (p->mode == ALILQR_MODE_LEGACY) || (p->n == 4);
   const int g0 = wide ? 32 : 16, g1 = wide ? 16 : 8;
+  // The LEGACY line search of the small models runs all of its up to 27 trials in one pass on 32 lanes; on 16 it needs a
+  // second pass whenever one group of the wave finds no step, and the last solves of a batch - each alone in its wave -
+  // take twice as long.  Measured at 40 960 and 81 920 lateral problems per launch: 32 lanes 228 k solves/s, 16 lanes 217 k.
+  if (p->mode == ALILQR_MODE_LEGACY && p->n <= 4) return g0;
   return ((long)p->batch * g0 / 64 <= target_waves) ? g0 : g1;
 }
 
@@ -513,6 +517,16 @@ static int32_t take_slot(int dev, hipStream_t st, size_t bytes, Slot** out) {
   return ALILQR_OK;
 }
 
+// Segments of alilqr_solve_batches: n_seg batches of seg_batch problems each, every one with buffers of its own.  The
+// solve runs once over all of them on contiguous staging arrays behind the scratch (same slot, same event ordering);
+// start states are gathered in front of the kernel and results scattered behind it with device-to-device copies.
+struct Segments {
+  int n_seg, seg_batch;
+  const double* const* x0;
+  double* const* x_out; double* const* u_out; double* const* node_x; double* const* node_u;
+  double* const* cost; double* const* viol; double* const* mu; int32_t* const* status;
+};
+
 static int32_t solve_impl(const alilqr_problem* p,
                           const double* x0, const double* goals,
                           const double* Q, const double* R, const double* cons,
@@ -522,7 +536,7 @@ static int32_t solve_impl(const alilqr_problem* p,
                           double* x_init, double* u_init,
                           double* cost, double* viol,
                           double* lam, double* mu,
-                          int32_t* status, void* stream, bool use_static) {
+                          int32_t* status, void* stream, bool use_static, const Segments* seg = nullptr) {
   const double* u_offset = ex ? ex->u_offset : nullptr;
   const int n_left = ex ? ex->n_left : 0, n_right = ex ? ex->n_right : 0;
   const bool rect = (n_left > 0) || (n_right > 0);
@@ -536,10 +550,8 @@ static int32_t solve_impl(const alilqr_problem* p,
   int32_t rc = check_problem(p, &d);
   if (rc != ALILQR_OK) return rc;
   if (p->batch == 0) return ALILQR_OK;   /* an empty batch is valid and touches nothing */
-  if (!x0 || !goals || !Q || !R || !cons || !x_out || !u_out || !cost) {
-    set_err("x0, goals, Q, R, cons, x_out, u_out, cost must not be null");
-    return ALILQR_E_ARG;
-  }
+  if (!seg && (!x0 || !x_out || !u_out || !cost)) { set_err("x0, x_out, u_out, cost must not be null"); return ALILQR_E_ARG; }
+  if (!goals || !Q || !R || !cons) { set_err("goals, Q, R, cons must not be null"); return ALILQR_E_ARG; }
   int dev = 0;
   {
     int n = 0;
@@ -552,6 +564,18 @@ static int32_t solve_impl(const alilqr_problem* p,
   if (pl.total == 0) {
     set_err("the scratch of one wave of this problem exceeds the static scratch (ALILQR_STATIC_SCRATCH_BYTES)");
     return ALILQR_E_NOMEM;
+  }
+  // staging arrays of a segmented solve, behind the scratch: x0 | x | u | node_x | node_u | cost | viol | mu | status
+  const size_t Bt = (size_t)p->batch, XSb = (size_t)(p->horizon + 1) * d.N * sizeof(double), USb = (size_t)p->horizon * d.M * sizeof(double);
+  size_t so[10] = {0};
+  if (seg) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t part[9] = {Bt * d.N * sizeof(double), Bt * XSb, Bt * USb, seg->node_x ? Bt * XSb : 0, seg->node_u ? Bt * USb : 0,
+                            Bt * sizeof(double), seg->viol ? Bt * sizeof(double) : 0, seg->mu ? Bt * sizeof(double) : 0,
+                            seg->status ? Bt * ALILQR_STATUS_WORDS * sizeof(int32_t) : 0};
+    so[0] = up(pl.total);
+    for (int i = 0; i < 9; ++i) so[i + 1] = up(so[i] + part[i]);
+    pl.total = so[9];
   }
 
   // The pool lock is held until the kernel is enqueued: nothing can free or re-assign the scratch in between.
@@ -584,6 +608,16 @@ static int32_t solve_impl(const alilqr_problem* p,
   HIP_TRY(hipMemsetAsync(base + pl.counter + 32, 0, 4, st));      /* violation bits of debug builds */
 #endif
 
+  if (seg) {
+    // the kernel works on the staging arrays; start states are gathered now, in stream order in front of it
+    x0 = (const double*)(base + so[0]); x_out = (double*)(base + so[1]); u_out = (double*)(base + so[2]);
+    node_x = seg->node_x ? (double*)(base + so[3]) : nullptr; node_u = seg->node_u ? (double*)(base + so[4]) : nullptr;
+    cost = (double*)(base + so[5]); viol = seg->viol ? (double*)(base + so[6]) : nullptr; mu = seg->mu ? (double*)(base + so[7]) : nullptr;
+    status = seg->status ? (int32_t*)(base + so[8]) : nullptr;
+    const size_t xb = (size_t)seg->seg_batch * d.N * sizeof(double);
+    for (int i = 0; i < seg->n_seg; ++i)
+      HIP_TRY(hipMemcpyAsync(base + so[0] + (size_t)i * xb, seg->x0[i], xb, hipMemcpyDeviceToDevice, st));
+  }
   alilqr::KArgs ka{};
   ka.B = p->batch; ka.NG = pl.NG; ka.H = p->horizon; ka.C = p->c;
   ka.goal_batch = p->goal_batch; ka.table_nodes = p->table_nodes;
@@ -601,7 +635,7 @@ static int32_t solve_impl(const alilqr_problem* p,
     if ((ex->first_rows || ex->overlay_out) && !rect) { set_err("first_rows / overlay_out need rectangle obstacles"); return ALILQR_E_ARG; }
     ka.mu_s_in = ex->mu_solver_in; ka.mu_s_out = ex->mu_solver_out; ka.first_rows = ex->first_rows; ka.overlay_out = ex->overlay_out;
   }
-  if (ex) ka.stop_after = ex->stop_after;
+  if (ex) { ka.stop_after = ex->stop_after; ka.order = ex->order; }
   if (rect) { ka.left_obs = ex->left_obs; ka.right_obs = ex->right_obs; ka.n_left = n_left; ka.n_right = n_right; ka.first_row = ex->first_row; }
   ka.x_out = x_out; ka.u_out = u_out; ka.node_x = node_x; ka.node_u = node_u;
   ka.x_init = x_init; ka.u_init = u_init; ka.cost = cost; ka.viol = viol; ka.lam = lam; ka.mu = mu;
@@ -634,6 +668,30 @@ static int32_t solve_impl(const alilqr_problem* p,
 #undef X
   if (lr == alilqr::LAUNCH_OK) {
     *counter_next += (unsigned)p->batch + (unsigned)pl.NG;
+    if (seg) {
+      // results back to the segments' own buffers, behind the kernel in stream order
+      const size_t sb = (size_t)seg->seg_batch;
+      hipError_t e = hipSuccess;
+      auto scatter = [&](void* const* dst, const void* src, size_t per_problem) {
+        if (!dst) return;
+        for (int i = 0; i < seg->n_seg && e == hipSuccess; ++i)
+          if (dst[i]) e = hipMemcpyAsync(dst[i], (const char*)src + (size_t)i * sb * per_problem, sb * per_problem, hipMemcpyDeviceToDevice, st);
+      };
+      scatter((void* const*)seg->x_out, x_out, XSb);
+      scatter((void* const*)seg->u_out, u_out, USb);
+      scatter((void* const*)seg->node_x, node_x, XSb);
+      scatter((void* const*)seg->node_u, node_u, USb);
+      scatter((void* const*)seg->cost, cost, sizeof(double));
+      scatter((void* const*)seg->viol, viol, sizeof(double));
+      scatter((void* const*)seg->mu, mu, sizeof(double));
+      scatter((void* const*)seg->status, status, ALILQR_STATUS_WORDS * sizeof(int32_t));
+      if (e != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        if (slot) { slot->used = true; slot->stream = st; slot->tick = ++g_tick; }
+        set_err("%s: %s", "hipMemcpyAsync(scatter)", hipGetErrorString(e));
+        return ALILQR_E_HIP;
+      }
+    }
     if (slot) {
       // the slot is in use from here on, whatever happens to the event: a later solve must wait for this kernel
       slot->used = true; slot->stream = st; slot->tick = ++g_tick;
@@ -678,6 +736,33 @@ int32_t alilqr_solve_batch_noalloc(const alilqr_problem* p,
                                    int32_t* status, void* stream) {
   return solve_impl(p, x0, goals, Q, R, cons, nullptr, x_out, u_out, node_x, node_u, x_init, u_init,
                     cost, viol, lam, mu, status, stream, true);
+}
+
+int32_t alilqr_solve_batches(const alilqr_problem* p, int32_t n_batches,
+                             const double* const* x0, const double* goals,
+                             const double* Q, const double* R, const double* cons,
+                             double* const* x_out, double* const* u_out,
+                             double* const* node_x, double* const* node_u,
+                             double* const* cost, double* const* viol, double* const* mu,
+                             int32_t* const* status, const int32_t* order, void* stream) {
+  if (!p) { set_err("null problem descriptor"); return ALILQR_E_ARG; }
+  if (n_batches < 0 || n_batches > 4096) { set_err("n_batches must be 0..4096"); return ALILQR_E_ARG; }
+  if (p->goal_batch != 1) { set_err("alilqr_solve_batches takes batches that share one goal list (goal_batch = 1)"); return ALILQR_E_ARG; }
+  if (n_batches == 0 || p->batch == 0) {
+    Dims d;
+    return check_problem(p, &d);
+  }
+  if (!x0 || !x_out || !u_out || !cost) { set_err("x0, x_out, u_out, cost pointer lists must not be null"); return ALILQR_E_ARG; }
+  for (int i = 0; i < n_batches; ++i)
+    if (!x0[i] || !x_out[i] || !u_out[i] || !cost[i]) { set_err("x0, x_out, u_out, cost of every batch must not be null"); return ALILQR_E_ARG; }
+  if ((long long)p->batch * n_batches > 0x7fffffffLL / 4) { set_err("too many problems in one call"); return ALILQR_E_ARG; }
+  alilqr_problem all = *p;
+  all.batch = p->batch * n_batches;
+  Segments seg{n_batches, p->batch, x0, x_out, u_out, node_x, node_u, cost, viol, mu, status};
+  alilqr_extras ex{};
+  ex.order = order;
+  return solve_impl(&all, nullptr, goals, Q, R, cons, &ex, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                    nullptr, nullptr, nullptr, nullptr, nullptr, stream, false, &seg);
 }
 
 int64_t alilqr_static_scratch_bytes(void) { return (int64_t)kStaticScratchBytes; }

@@ -189,6 +189,7 @@ struct KArgs {
   const int32_t* first_rows;  // RECT, optional [H+1]: per-node initial row index (null: first_row)
   double* overlay_out;        // RECT, optional [B][H+1][2C+1]: row signs | replacement constants | row index per node
   const int32_t* stop_after;  // optional [B]: inner iteration after which a problem ends (diagnostic), or null
+  const int32_t* order;       // optional [B]: permutation in which the problems are pulled (scheduling hint), or null
   double *x_out, *u_out, *node_x, *node_u, *x_init, *u_init, *cost, *viol, *lam, *mu;
   int32_t* status;
   double *trj, *blk, *ucum;
@@ -1430,6 +1431,11 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         drained = true;
       } else {
         p = np;
+        {
+          // scheduling hint: the np-th pull takes problem order[np] (read from the argument block here, see ALILQR_COLD)
+          const int32_t* const ord = ALILQR_COLD_(order);
+          if (ord) { const int q = ord[np]; if ((unsigned)q < (unsigned)ALILQR_COLD(B)) p = q; }
+        }
         const double* goals = a.goals + ((a.goal_batch > 1) ? (size_t)p * XS : 0);
         // outputs / optional inputs of the initial guess, read from the argument block here (see ALILQR_COLD)
         double* const o_xi = ALILQR_COLD(x_init);

@@ -252,6 +252,12 @@ typedef struct alilqr_extras {
    * ALILQR_FLAG_STOPPED.  A solve that ends earlier by its own rules is not affected.  Lets a test compare the
    * iterate of a chosen iteration with the reference's instead of only the end of the solve. */
   const int32_t* stop_after;
+  /* Scheduling hint (no counterpart in the reference): order [B] or NULL, a permutation of 0 .. B-1.  The resident
+   * lane groups pull the problems in this order instead of 0, 1, 2 ...  Results do not depend on it.  A batch ends
+   * when its last solve ends; with the problems that take longest first (e.g. by the inner-iteration counts,
+   * status[0], the same problems needed in the previous planning cycle) the short solves fill the end of the batch
+   * instead of one long solve running alone.  An entry outside 0 .. B-1 is replaced by its own position. */
+  const int32_t* order;
 } alilqr_extras;
 
 /* alilqr_solve_batch with the optional inputs above (ex may be NULL). */
@@ -325,6 +331,31 @@ int32_t alilqr_constraints_batch(const alilqr_problem* p,
                                  const double* goals, const double* Q, const double* R, const double* cons,
                                  double* cval, double* par_cval, double* jac_x, double* jac_u,
                                  void* stream);
+
+/*
+ * Many batches in one call.  A caller that serves independent requests holds one set of buffers per request (per
+ * planning cycle, per client); solving them one alilqr_solve_batch at a time leaves the GPU idle while the longest
+ * solve of each batch finishes, unless the caller keeps many streams busy.  This entry point takes n_batches batches
+ * of p->batch problems each - same model, generation, horizon, goals and tables; start states and outputs in buffers
+ * of their own - and solves them as ONE batch: the resident lane groups pull problems of all batches from one queue,
+ * so a batch's stragglers overlap with the other batches' work.  Every problem gets the bits alilqr_solve_batch gives
+ * it.  The reference has no batch driver; per problem this is optimize() as in alilqr_solve_batch.
+ *   x0, x_out, u_out, cost            HOST arrays of n_batches DEVICE pointers: [B][n], [B][H+1][n], [B][H][m], [B]
+ *   node_x, node_u, viol, mu, status  the same, optional: the list, or single entries of it, may be NULL
+ *   goals, Q, R, cons                 device pointers shared by all batches (p->goal_batch must be 1)
+ * The start states are gathered into, and the results scattered from, staging arrays inside the library's scratch with
+ * device-to-device copies on `stream` (2.1 KB per lateral problem: microseconds per batch).  Asynchronous like
+ * alilqr_solve_batch: outputs are valid once the stream drains; the pointer lists are read before the call returns.
+ *   order  optional DEVICE array [n_batches * B]: a permutation of the problems of all batches (problem b of batch i
+ *          is i * B + b) in which they are pulled, see alilqr_extras::order; NULL = as they lie.
+ */
+int32_t alilqr_solve_batches(const alilqr_problem* p, int32_t n_batches,
+                             const double* const* x0, const double* goals,
+                             const double* Q, const double* R, const double* cons,
+                             double* const* x_out, double* const* u_out,
+                             double* const* node_x, double* const* node_u,
+                             double* const* cost, double* const* viol, double* const* mu,
+                             int32_t* const* status, const int32_t* order, void* stream);
 
 /* Release every cached device workspace of the calling process (waits for the solves in flight). */
 int32_t alilqr_release(void);

@@ -63,3 +63,62 @@ def test_solver_runs_on_its_own_device():
     torch.cuda.synchronize(last)
     for k in ("x", "u", "cost"):
         assert np.array_equal(sv.out[k].cpu().numpy(), ref[k]), k
+
+
+def test_many_batches_in_one_call_give_the_bits_of_separate_calls():
+    """alilqr_solve_batches: batches with buffers of their own solved as one batch (staging gather / scatter inside the
+    library) - every problem gets the bits alilqr_solve_batch gives it; optional outputs may be left out per list."""
+    import torch
+    import ctypes as C
+    seeds = (31, 32, 33, 34, 35)
+    probs = [problems.lat_legacy(200, 50, seed=s) for s in seeds]
+    want = [{k: v.cpu().numpy() for k, v in batch.solve_batch(*p).items()} for p in probs]
+    desc, _, goals, Q, R, cons = probs[0]
+    for extras in (False, True):
+        mb = batch.MultiBatchSolver(desc, [p[1] for p in probs], goals, Q, R, cons, extras=extras)
+        for rep in range(2):                            # the second call reuses the scratch slot and its staging
+            outs = mb.run()
+            torch.cuda.synchronize()
+            for o, w in zip(outs, want):
+                for k in o:
+                    assert np.array_equal(o[k].cpu().numpy(), w[k], equal_nan=True), (extras, rep, k)
+    # a 6-state generation with a table, and an empty list
+    fp = [problems.fast_box_linear(40, H=50, seed=s) for s in (5, 6, 7)]
+    fw = [{k: v.cpu().numpy() for k, v in batch.solve_batch(*p).items()} for p in fp]
+    mb = batch.MultiBatchSolver(fp[0][0], [p[1] for p in fp], *fp[0][2:], extras=True)
+    outs = mb.run()
+    torch.cuda.synchronize()
+    for o, w in zip(outs, fw):
+        for k in o:
+            assert np.array_equal(o[k].cpu().numpy(), w[k], equal_nan=True), k
+    lib = capi.load_library()
+    assert lib.alilqr_solve_batches(C.byref(desc), 0, *([None] * 15)) == 0
+    bad = type(desc).from_buffer_copy(desc)
+    bad.goal_batch = bad.batch
+    assert lib.alilqr_solve_batches(C.byref(bad), 1, *([None] * 15)) == capi.E_ARG
+
+
+def test_pull_order_hint_changes_nothing_but_the_schedule(tuning):
+    """alilqr_extras::order / the order argument of alilqr_solve_batches: any permutation, with fewer resident groups
+    than problems, gives every problem the same bits; entries outside the batch are ignored."""
+    import torch
+    tuning(lanes=32, max_waves=8)                      # 16 groups for 150 problems: the order really decides who runs when
+    prob = problems.lat_legacy(150, 50, seed=61)
+    ref = _np(batch.solve_batch(*prob))
+    by_work = np.argsort(-ref["status"][:, 0], kind="stable").astype(np.int32)
+    for order in (by_work, by_work[::-1].copy(), np.random.default_rng(3).permutation(150).astype(np.int32)):
+        o = _np(batch.solve_batch(*prob, order=order))
+        for k in ref:
+            assert np.array_equal(o[k], ref[k], equal_nan=True), k
+    junk = by_work.copy(); junk[7] = -5; junk[9] = 150
+    bad = _np(batch.solve_batch(*prob, order=junk))    # no fault; the two positions fall back to their own index
+    assert np.isfinite(bad["cost"][by_work[:5]]).all()
+    tuning()
+    mb = batch.MultiBatchSolver(prob[0], [prob[1], problems.lat_legacy(150, 50, seed=62)[1]], *prob[2:6])
+    a = [_np(o) for o in mb.run()]
+    torch.cuda.synchronize()
+    b = [_np(o) for o in mb.run(order=mb.order_by_last_solve())]
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        for k in x:
+            assert np.array_equal(x[k], y[k], equal_nan=True), k

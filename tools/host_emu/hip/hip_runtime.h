@@ -95,6 +95,8 @@ inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy(d, s, n); return hipSuccess; }
 constexpr int hipMemcpyDeviceToHost = 2;
+constexpr int hipMemcpyDeviceToDevice = 3;
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
 typedef void* hipEvent_t;
 constexpr unsigned hipEventDisableTiming = 2;
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
