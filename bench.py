@@ -401,7 +401,9 @@ def main():
             "roofline": {"bound": "valu_fp64", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / FP64_VALU_PEAK_TFLOPS,
                          # HBM bytes per launch from the PMC passes of this build (null when none is committed for it)
-                         "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+                         # (measured per solve on launches of the configuration's batch, times the problems of this launch)
+                         "traffic": (pmc["hbm_bytes_per_solve"] * B * last_n) if pmc and pmc.get("hbm_bytes_per_solve") else
+                                    (pmc.get("hbm_bytes_per_launch") if pmc else None),
                          "counters": pmc,
                          # kernel_ms is a launch as it experienced the machine: `launches_in_flight` launches share the GPU, so
                          # a launch lasts about that many times its share; achieved_job / frac_job are the algorithmic

@@ -52,19 +52,25 @@ inline int launch_family(const KArgs& ka, int G, int waves, hipStream_t st, int 
         const int cols = ntrials > 2 ? ntrials - 2 : 0;
         const size_t both = 2 * lds_group_doubles(ka.H, E, cols * MDx::M) * sizeof(double);
         const size_t share = (MDx::N <= 4) ? 160 * 1024 / 8 : 160 * 1024 / 4;
+        KArgs k2 = ka;
+        k2.lds_bytes = (int)lds;
         if (packed32) {
-          hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32, 3>), grid, block, lds, st, ka);
+          hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32, 3>), grid, block, lds, st, k2);
         } else if (both <= share && !ALILQR_NO_LDS_UCUM) {
-          KArgs k2 = ka;
           k2.uc_cols = cols;
+          k2.lds_bytes = (int)both;
           hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32, 2>), grid, block, both, st, k2);
         } else {
-          hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32, 1>), grid, block, lds, st, ka);
+          hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32, 1>), grid, block, lds, st, k2);
         }
-      } else if (G == 16) hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 16, 1>), grid, block, lds, st, ka);
-      else {
-        if constexpr (MDx::N <= 4) hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 8, 1, 1>), grid, block, lds, st, ka);
-        else return LAUNCH_BAD_WIDTH;
+      } else {
+        KArgs k2 = ka;
+        k2.lds_bytes = (int)lds;
+        if (G == 16) hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 16, 1>), grid, block, lds, st, k2);
+        else {
+          if constexpr (MDx::N <= 4) hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 8, 1, 1>), grid, block, lds, st, k2);
+          else return LAUNCH_BAD_WIDTH;
+        }
       }
       return hipGetLastError() == hipSuccess ? LAUNCH_OK : LAUNCH_FAILED;
     }

@@ -196,6 +196,7 @@ struct KArgs {
   unsigned int* counter;      // problem counter of the scratch, never reset: this solve's problems are
   unsigned int counter_base;  // counter - counter_base = 0 .. B-1 (the host knows the value every solve leaves behind)
   unsigned long long* prof;   // optional phase cycle counters (profiling builds only)
+  int lds_bytes;              // dynamic LDS of the launch (bounds-checked builds compare the pool indices with it)
 };
 
 // ---- lane-group primitives ---------------------------------------------------
@@ -1276,6 +1277,10 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   // doubles of a group's share of the pool (the host sizes the launch with the same expression: lds_group_doubles)
   const size_t PGS = lds_group_doubles(H, NR::E, LDSUC ? a.uc_cols * M : 0);
   double* const linb = LDSLIN ? lds_pool + (size_t)(lane / G) * PGS : blk + (size_t)(H + 1) * RS * ES;
+  // bounds-checked builds: the wave's groups fit the launch's LDS; a group's share holds its records and (later in the
+  // iteration) its accumulated controls
+  (void)ALILQR_CHK(!LDSLIN || (size_t)(64 / G) * PGS * sizeof(double) <= (size_t)a.lds_bytes, 16);
+  (void)ALILQR_CHK(!LDSLIN || ((size_t)(H + 1) * NR::E <= PGS && (!LDSUC || (size_t)H * M * (size_t)(a.uc_cols > 0 ? a.uc_cols : 1) <= PGS)), 17);
 
   double* const trj = a.trj;
   const int cw = LEGACY ? (2 * N + 2 * M) : C * (N + M + 1) + (QUAD ? C * N * N : 0);   // doubles per constraint table
@@ -1374,13 +1379,22 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   auto tabR = [&](int) { return (ctab)kLitR; };
   auto tabC = [&](int) { return (ctab)kLitB; };
 #else
-  auto tabQ = [&](int t) { return as_ctab(a.Q) + (size_t)((a.table_nodes > 1) ? t : 0) * N * N; };
-  auto tabR = [&](int t) { return as_ctab(a.R) + (size_t)((a.table_nodes > 1) ? t : 0) * M * M; };
-  auto tabC = [&](int t) { return as_ctab(a.cons) + (size_t)((a.table_nodes > 1) ? t : 0) * cw; };
+  // (bounds-checked builds: the node index of a per-node table, and the problem index of a per-problem goal list, are
+  //  caller-input indices like the workspace offsets above)
+  auto tnode = [&](int t) -> int {
+    if (!ALILQR_CHK(t >= 0 && t <= H, 14)) t = 0;
+    return (a.table_nodes > 1) ? t : 0;
+  };
+  auto tabQ = [&](int t) { return as_ctab(a.Q) + (size_t)tnode(t) * N * N; };
+  auto tabR = [&](int t) { return as_ctab(a.R) + (size_t)tnode(t) * M * M; };
+  auto tabC = [&](int t) { return as_ctab(a.cons) + (size_t)tnode(t) * cw; };
 #endif
 
   // goal list of problem q (clamped: idle groups still form addresses)
-  auto goal_of = [&](int q) -> const double* { return a.goals + ((a.goal_batch > 1 && q > 0) ? (size_t)q * XS : 0); };
+  auto goal_of = [&](int q) -> const double* {
+    if (!ALILQR_CHK(q < ALILQR_COLD_(B), 15)) q = 0;
+    return a.goals + ((a.goal_batch > 1 && q > 0) ? (size_t)q * XS : 0);
+  };
   // node t of the current trajectory (slot of the last accepted roll-out)
   auto load_node = [&](int t, double* x, double* u) {
 #pragma unroll
