@@ -5,7 +5,7 @@ the others (chaotic iterates, line searches decided by rounding) would be covere
 compared, iteration by iteration, for as long as it is comparable: up to the first iteration at which the GPU, or one
 of three oracle runs from start states moved by ~1e-13, takes another number of line-search trials than the oracle.
 Inside that prefix the GPU's cost after every iteration must stay within the envelope of the oracle's own
-sensitivity: |J_gpu - J| <= max(1e-9 |J|, 1e3 x the largest |J_probe - J| of the three moved runs); the first
+sensitivity: |J_gpu - J| <= max(1e-9 |J|, 30 x the largest |J_probe - J| of the three moved runs; 300 x on one set, see ENV_SET); the first
 iteration (same start, one linearisation, one backward sweep, one line search) to 1e-10 |J| or that envelope.
 Reference for what is traced: the cost / trial prints of cilqr/ilqr.py:157-167, fast_ilqr.py:142-152 and the
 iteration loop of al_ilqr_cpp/new_al_ilqr.h:1090-1122.
@@ -19,6 +19,10 @@ from ilqr_amd import batch, problems
 
 pytestmark = pytest.mark.gpu
 CAP = 512
+# The GPU's cost may differ from the oracle's by ENV times the oracle's own spread over three moved start states (or by
+# 1e-9 |J|).  Three probes under-estimate a spread, so the factor is above 1; measured on MI355X the largest ratio is
+# 0.0 .. 13 on nine of the ten sets and 185 on one solve of new_al_circle6 (4.5e-8 against a probe spread of 2.4e-10).
+ENV_DEFAULT, ENV_SET = 30.0, {"new_al_circle6": 300.0}
 
 SETS = {
     "lat_legacy": lambda: problems.lat_legacy(96, 50, seed=0),
@@ -52,7 +56,8 @@ def test_iteration_trace_stays_inside_the_oracles_own_sensitivity(name):
     rng = np.random.default_rng(7)
     probes = [ol.solve_batch_traced(desc, x0 + rng.uniform(-1, 1, size=x0.shape) * 1e-13, *prob[2:6], capacity=CAP)
               for _ in range(3)]
-    covered, total, whole = 0, 0, 0
+    covered, total, whole, worst = 0, 0, 0, 0.0
+    ENV = ENV_SET.get(name, ENV_DEFAULT)
     for i in range(B):
         n_or = len(oc[i])
         L = min(n_or, min(CAP, int(st[i, 0])))
@@ -67,11 +72,13 @@ def test_iteration_trace_stays_inside_the_oracles_own_sensitivity(name):
             env = np.maximum(env[:L], rel(pc[i][:L], oc[i][:L]))
         e = rel(gc[i, :L], oc[i][:L])
         assert L >= 1, (name, i, "not even the first iteration is comparable")
-        assert e[0] < max(1e-10, 1e3 * env[0]), (name, i, e[0], env[0])
-        bad = np.nonzero(e > np.maximum(1e-9, 1e3 * env))[0]
+        assert e[0] < max(1e-10, ENV * env[0]), (name, i, e[0], env[0])
+        bad = np.nonzero(e > np.maximum(1e-9, ENV * env))[0]
+        worst = max(worst, float(np.max(e / np.maximum(1e-9, env)))) if L else worst
         assert len(bad) == 0, (name, i, int(bad[0]), e[bad[0]], env[bad[0]])
         covered += L; total += n_or; whole += (L == n_or and int(st[i, 0]) == n_or)
     gu.PINNED_LOG.append((f"trace/{name}: iterations compared", covered, total))
     gu.PINNED_LOG.append((f"trace/{name}: solves compared to their last iteration", whole, B))
-    print(f"[trace] {name}: {covered}/{total} iterations compared ({covered / max(1, total):.3f}), {whole}/{B} solves to the end")
+    print(f"[trace] {name}: {covered}/{total} iterations compared ({covered / max(1, total):.3f}), {whole}/{B} solves to the end; "
+          f"largest error / max(1e-9, oracle's own spread) = {worst:.2f}")
     assert covered >= 0.05 * total
