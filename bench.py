@@ -308,7 +308,8 @@ def main():
     if group > 1 and not args.no_order_hint:
         spread = np.array([0.0, 1.0, 0.2, 0.05]) if n == 4 else np.array([0.0, 1.0, 0.1, 0.0, 1.0, 0.0])
         rng = np.random.default_rng(12345 + rank)
-        prev_x0s = [np.asarray(x) + 0.01 * spread * rng.standard_normal(np.asarray(x).shape) for x in x0s]
+        moved = float(os.environ.get("ALILQR_BENCH_HINT_SPREAD", "0.01"))     # development: 0 = a perfect hint
+        prev_x0s = [np.asarray(x) + moved * spread * rng.standard_normal(np.asarray(x).shape) for x in x0s]
         prev = batch.MultiBatchSolver(desc, prev_x0s, *prob[2:6], extras=False, device=dev)
         prev.run()
         torch.cuda.synchronize(dev)

@@ -1203,6 +1203,9 @@ __host__ __device__ inline size_t block_doubles(int H, int C) {
 #ifndef ALILQR_TRIP_N6
 #define ALILQR_TRIP_N6 0   // per-trip passes for the 6-state kernels too (measured slower: their register allocation suffers)
 #endif
+#ifndef ALILQR_LEGACY_ROUNDS
+#define ALILQR_LEGACY_ROUNDS 0   // 1: LEGACY groups narrower than 32 lanes take their trials in rounds on the group's own lanes, one round per trip (measured: same bits, same throughput as the wave-wide passes - lateral 218 k against 217 k at 16 lanes, dynamic H = 100 50.5 k against 52.2 k)
+#endif
 #ifndef ALILQR_MINW_N4
 #define ALILQR_MINW_N4 2   // waves per SIMD the 4-state kernels are compiled for (256 registers per lane)
 #endif
@@ -1253,6 +1256,10 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   // need different numbers of passes); with two groups per wave the passes of a line search run back to back,
   // which also keeps the register allocation of the 6-state kernels tight.
   constexpr bool TRIP = (G < 32) && (N <= 4 || ALILQR_TRIP_N6);
+  // LEGACY line search: wave-wide passes (below), or - a development switch, ALILQR_LEGACY_ROUNDS - for groups narrower
+  // than 32 lanes the trials in rounds of G on the group's OWN lanes, one round per roll-out pass of the wave, through
+  // the state machine of the other generations.
+  constexpr bool LWIDE = LEGACY && !(G < 32 && ALILQR_LEGACY_ROUNDS);
   constexpr bool PM = true;                            // block layout: problem-major (one contiguous block per group)
   constexpr int CL = LEGACY ? (MD::CTRL_ROWS ? 2 * (N + M) : 2 * N) : 1;         // multipliers held in registers (LEGACY only)
   constexpr int SS = TrjSlots<MODE>::SS;               // trajectory slots kept per problem and parity
@@ -2012,7 +2019,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         for (int q = 1; q < j && q < 64; ++q) al = al / 2.0;
         return al;
       };
-      if constexpr (LEGACY) {
+      if constexpr (LWIDE) {
         // ---- LEGACY line search, wave-wide.  Trial 1 is the closed-loop step; trials >= 2 run open loop on
         //      accumulated controls (ilqr.py:119 with new_u aliasing u after the first rejected step).
         //      Pass A: every group rolls out its first G trials on its own lanes.  Passes B: the trials that are
@@ -2150,7 +2157,30 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           stage = ST_DONE;
         }
       } else if (p >= 0) {
-        const Tgt own{blk, trj + ((gid * 2 + (size_t)np_) * SS) * (size_t)T, trj_at(cur_par, 0, ref_slot), goal_of(p), mu, 0ull, 0ull};
+        const Tgt own{blk, trj + ((gid * 2 + (size_t)np_) * SS) * (size_t)T, trj_at(cur_par, 0, ref_slot), goal_of(p), mu,
+                      LEGACY ? lmask0 : 0ull, LEGACY ? lmask1 : 0ull};
+        // LEGACY: trial 1 is the closed-loop step, trials >= 2 run open loop on accumulated controls (ilqr.py:119 with
+        // new_u aliasing u after the first rejected step); the controls of trials 2 .. ntrials are formed, nodes in
+        // parallel, when the search starts:  u_j = u_{j-1} + 2^-(j-1) k
+        static_assert(!(LEGACY && LDSUC), "accumulated controls in LDS belong to the wave-wide search of 32-lane groups");
+        const size_t UCSr = LEGACY ? (size_t)(ntrials > 1 ? ntrials - 1 : 1) : 0;
+        double* const ucgr = LEGACY ? a.ucum + gid * (UCSr * US) : nullptr;      // [t * M + r][trial - 2]
+        if (LEGACY && stage == ST_TRIALS && r0 == 0) {
+          for (int t = gl; t < H; t += G) {
+            const double* rt = rec(t);
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+              const double kf = rt[(size_t)(RL::rk + r) * ES];
+              double sacc = *trj_at(cur_par, XS + t * M + r, cur_slot);
+              double al = alpha_of(2);
+              for (int i = 2; i <= ntrials; ++i) {
+                sacc = sacc + al * kf;
+                al = al / 2.0;
+                ucgr[(size_t)(t * M + r) * UCSr + (i - 2)] = sacc;
+              }
+            }
+          }
+        }
       // The passes of the line search (rounds of trials, the C++ generation's ladder, the repeat of a winner
       // whose trajectory was not kept) go through ONE roll-out call: the groups of a wave that are in
       // different passes still execute it together, and the roll-out code exists once.
@@ -2158,10 +2188,12 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         bool valid = true;
         int kind = 0, sslot = -1;
         double alpha = 1.0;
+        int uct = 2;                             // LEGACY: the trial whose accumulated controls this lane reads
         if (stage == ST_TRIALS) {
           const int j = r0 + gl + 1;             // trial number, 1-based
           valid = j <= ntrials;
-          alpha = alpha_of(j);
+          if (LEGACY) { kind = (j != 1) ? 1 : 0; alpha = 1.0; uct = (valid && j >= 2) ? j : 2; }
+          else alpha = alpha_of(j);
           sslot = valid ? store_slot(j) : -1;
         } else if (stage == ST_LADDER) {
           // five-wide ladder alpha, alpha/3, ... from alpha = 2^-10 (new_al_ilqr.h:818-898)
@@ -2174,9 +2206,10 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           // every lane of the group repeats the winner's roll-out, lane 0 keeps it in the spare slot
           kind = replay_kind; alpha = replay_alpha;
           sslot = (gl == 0) ? SS - 1 : -1;
+          if (LEGACY) uct = (win_trial >= 2) ? win_trial : 2;
         }
         __threadfence_block();
-        const double J = rollout(own, valid, kind, alpha, nullptr, 0, sslot);
+        const double J = rollout(own, valid, kind, alpha, LEGACY ? ucgr + (uct - 2) : nullptr, UCSr, sslot);
 
         if (stage == ST_TRIALS) {
           const bool ok = valid && (J < old_cost);
@@ -2195,8 +2228,8 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           if (win_trial >= 0) {
             const int ws = store_slot(win_trial);
             if (ws < 0) {
-              replay_kind = 0;
-              replay_alpha = alpha_of(win_trial);
+              replay_kind = (LEGACY && win_trial != 1) ? 1 : 0;
+              replay_alpha = LEGACY ? 1.0 : alpha_of(win_trial);
               cur_slot = SS - 1;
               stage = ST_REPLAY;
             } else {
@@ -2214,6 +2247,11 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
               stage = ST_DONE;
             }
           } else {
+            if (LEGACY) {
+              // every step rejected: the reference is left holding the last trial's arrays (ilqr.py:137-147)
+              win_trial = ntrials; new_cost = J_last;
+              cur_slot = store_slot(ntrials);
+            }
             stage = ST_DONE;
           }
         } else if (stage == ST_LADDER) {
