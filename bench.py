@@ -10,7 +10,7 @@ vectors over RCCL at the end of the K steps is the only exchange.
 Consecutive steps are independent batches (each with start states and output buffers of its own).  A batch ends
 when its longest solve ends, so batches solved one call at a time leave the SIMDs idle during every tail.  Two ways
 to keep the machine full:
-  --group G (default 10; configurations 2, 4a, 4b)  G consecutive steps are handed to the library in ONE call
+  --group G (default 20; configurations 2, 4a, 4b)  G consecutive steps are handed to the library in ONE call
       (alilqr_solve_batches): it solves them as one batch, the resident lane groups pull problems of all G batches
       from one queue.  --pipeline calls (default 2) are in flight on as many streams, so the tail of one call
       overlaps with the next.  Needs no more than HIP's default hardware queues.
@@ -85,9 +85,9 @@ def algorithmic_bytes(desc):
 
 
 def kernel_source_id():
-    """Hash of the kernel sources: counters measured on another build are not reported as this build's."""
+    """Hash of the solve kernel's sources: counters measured on another build are not reported as this build's."""
     h = hashlib.sha1()
-    for f in ("solver.hpp", "models.hpp", "trig.hpp", "launch.hpp", "alilqr_api.hip"):
+    for f in ("solver.hpp", "models.hpp", "trig.hpp", "launch.hpp"):
         with open(os.path.join(ROOT, "ilqr_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--max-waves", type=int, default=0,
                     help="resident waves per launch (0 = the library's choice); with fewer waves than problem pairs a lane "
                          "group pulls its next problem when it finishes one")
-    ap.add_argument("--group", type=int, default=10,
+    ap.add_argument("--group", type=int, default=20,
                     help="steps (batches) per library call: 1 = one alilqr_solve_batch per step; > 1 = alilqr_solve_batches")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="calls in flight (HIP streams used in turn); 0 = 2 with --group > 1, 12 with --group 1")
@@ -326,9 +326,10 @@ def main():
                 "source": "inner-iteration counts of the same batches solved, outside the timed region, from start states "
                           "moved by 1 % of their spread (the previous cycle of a planning loop); longest first",
                 "rank_correlation_with_actual_counts": float(np.corrcoef(ra, rb)[0, 1])}
-    # per-problem status words of the last call's batches (the algorithmic operation count comes from them)
-    last_n = plan[-1]
-    outs = sv.out[:last_n] if group > 1 else [sv.out]
+    # per-problem status words of the first call's batches (the algorithmic operation count comes from them); a later,
+    # smaller call on the same stream slot re-solves a prefix of the same batches and leaves the same words
+    last_n = plan[0]
+    outs = solvers[0].out[:last_n] if group > 1 else [solvers[0].out]
     out = outs[0]
 
     # outside the timed region: the same launch alone on the device, for the record
@@ -350,7 +351,7 @@ def main():
     light_ms = e0.elapsed_time(e1)
     light_iters = int(lout["status"][:, 0].max().item())
 
-    # a launch = one library call = `steps_per_launch` steps; duration of the last call's size class only
+    # a launch = one library call = `steps_per_launch` steps; duration of the first call's size class only
     full = [i for i, n_ in enumerate(plan) if n_ == last_n]
     kernel_ms = float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in full]))
     status = np.concatenate([o["status"].cpu().numpy() for o in outs])

@@ -224,6 +224,35 @@ __global__ void analyze_rows_kernel(const double* tab, int C, int N, int M, unsi
   if (i == 0) *out = all_ok ? (unsigned)nbox : 0u;
 }
 
+// Gather / scatter between the per-batch buffers of alilqr_solve_batches and the contiguous staging arrays the solve
+// works on: one launch moves one array of up to 64 batches (8-byte words; blockIdx.y = batch).
+struct SegPtrs { void* p[64]; };
+__global__ __launch_bounds__(256) void seg_copy_kernel(SegPtrs seg, unsigned long long* staging, size_t words_per_seg, int to_segments) {
+  unsigned long long* const own = (unsigned long long*)seg.p[blockIdx.y];
+  if (!own) return;
+  unsigned long long* const st = staging + (size_t)blockIdx.y * words_per_seg;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words_per_seg; i += (size_t)gridDim.x * blockDim.x) {
+    if (to_segments) own[i] = st[i]; else st[i] = own[i];
+  }
+}
+// move one array between `n_seg` per-batch buffers and its staging array (bytes_per_seg is a multiple of 8)
+hipError_t seg_copy(void* const* ptrs, void* staging, size_t bytes_per_seg, int n_seg, bool to_segments, hipStream_t st) {
+  const size_t words = bytes_per_seg / 8;
+  for (int s0 = 0; s0 < n_seg; s0 += 64) {
+    SegPtrs sp{};
+    const int n = (n_seg - s0 < 64) ? n_seg - s0 : 64;
+    for (int i = 0; i < n; ++i) sp.p[i] = ptrs[s0 + i];
+    unsigned bx = (unsigned)((words + 255) / 256);
+    if (bx > 1024) bx = 1024;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(seg_copy_kernel, dim3(bx, (unsigned)n), dim3(256), 0, st, sp,
+                       (unsigned long long*)((char*)staging + (size_t)s0 * bytes_per_seg), words, to_segments ? 1 : 0);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 // Layout of a solve's scratch.  `cap` > 0 bounds the total: the number of resident waves is reduced until the
 // scratch fits (the groups then pull more problems each); total == 0 says that not even one wave fits.
 Plan make_plan(const alilqr_problem* p, const Dims& d, bool rect = false, size_t cap = 0) {
@@ -614,9 +643,7 @@ static int32_t solve_impl(const alilqr_problem* p,
     node_x = seg->node_x ? (double*)(base + so[3]) : nullptr; node_u = seg->node_u ? (double*)(base + so[4]) : nullptr;
     cost = (double*)(base + so[5]); viol = seg->viol ? (double*)(base + so[6]) : nullptr; mu = seg->mu ? (double*)(base + so[7]) : nullptr;
     status = seg->status ? (int32_t*)(base + so[8]) : nullptr;
-    const size_t xb = (size_t)seg->seg_batch * d.N * sizeof(double);
-    for (int i = 0; i < seg->n_seg; ++i)
-      HIP_TRY(hipMemcpyAsync(base + so[0] + (size_t)i * xb, seg->x0[i], xb, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(seg_copy((void* const*)seg->x0, base + so[0], (size_t)seg->seg_batch * d.N * sizeof(double), seg->n_seg, false, st));
   }
   alilqr::KArgs ka{};
   ka.B = p->batch; ka.NG = pl.NG; ka.H = p->horizon; ka.C = p->c;
@@ -672,10 +699,9 @@ static int32_t solve_impl(const alilqr_problem* p,
       // results back to the segments' own buffers, behind the kernel in stream order
       const size_t sb = (size_t)seg->seg_batch;
       hipError_t e = hipSuccess;
-      auto scatter = [&](void* const* dst, const void* src, size_t per_problem) {
-        if (!dst) return;
-        for (int i = 0; i < seg->n_seg && e == hipSuccess; ++i)
-          if (dst[i]) e = hipMemcpyAsync(dst[i], (const char*)src + (size_t)i * sb * per_problem, sb * per_problem, hipMemcpyDeviceToDevice, st);
+      auto scatter = [&](void* const* dst, void* src, size_t per_problem) {
+        if (!dst || e != hipSuccess) return;
+        e = seg_copy(dst, src, sb * per_problem, seg->n_seg, true, st);
       };
       scatter((void* const*)seg->x_out, x_out, XSb);
       scatter((void* const*)seg->u_out, u_out, USb);
@@ -688,7 +714,7 @@ static int32_t solve_impl(const alilqr_problem* p,
       if (e != hipSuccess) {
         (void)hipStreamSynchronize(st);
         if (slot) { slot->used = true; slot->stream = st; slot->tick = ++g_tick; }
-        set_err("%s: %s", "hipMemcpyAsync(scatter)", hipGetErrorString(e));
+        set_err("%s: %s", "scatter launch", hipGetErrorString(e));
         return ALILQR_E_HIP;
       }
     }

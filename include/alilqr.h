@@ -343,8 +343,10 @@ int32_t alilqr_constraints_batch(const alilqr_problem* p,
  *   x0, x_out, u_out, cost            HOST arrays of n_batches DEVICE pointers: [B][n], [B][H+1][n], [B][H][m], [B]
  *   node_x, node_u, viol, mu, status  the same, optional: the list, or single entries of it, may be NULL
  *   goals, Q, R, cons                 device pointers shared by all batches (p->goal_batch must be 1)
- * The start states are gathered into, and the results scattered from, staging arrays inside the library's scratch with
- * device-to-device copies on `stream` (2.1 KB per lateral problem: microseconds per batch).  Asynchronous like
+ * The start states are gathered into, and the results scattered from, staging arrays inside the library's scratch by
+ * small copy kernels on `stream` (one launch per array; 2.1 KB per lateral problem: microseconds per batch).  They are
+ * ordinary kernels: while ANOTHER call's solve keeps every SIMD occupied they wait for its waves to finish, so results
+ * of overlapping calls become visible late; a latency-sensitive caller keeps one call in flight.  Asynchronous like
  * alilqr_solve_batch: outputs are valid once the stream drains; the pointer lists are read before the call returns.
  *   order  optional DEVICE array [n_batches * B]: a permutation of the problems of all batches (problem b of batch i
  *          is i * B + b) in which they are pulled, see alilqr_extras::order; NULL = as they lie.
