@@ -87,7 +87,7 @@ def algorithmic_bytes(desc):
 def kernel_source_id():
     """Hash of the solve kernel's sources: counters measured on another build are not reported as this build's."""
     h = hashlib.sha1()
-    for f in ("solver.hpp", "models.hpp", "trig.hpp", "launch.hpp"):
+    for f in ("solver.hpp", "models.hpp", "trig.hpp", "launch.hpp", "solve_family.hip"):
         with open(os.path.join(ROOT, "ilqr_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]

@@ -24,6 +24,8 @@ def main():
         "new_al kin+linear H50": problems.kin_linear(B),
         "new_al circle6 H50": problems.new_al_circle(B),
         "new_al kin+rect H50": problems.kin_rect(B),
+        "new_al lat4 circle H30": problems.new_al_lat_circle(B),
+        "new_al lat4 rect H50": problems.new_al_lat_rect(B),
     }
     only = sys.argv[1:]
     for name, prob in sets.items():
