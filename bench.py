@@ -303,7 +303,7 @@ def main():
     # cycle after cycle, problems that differ little from the previous cycle's; the inner-iteration counts of the
     # previous cycle predict this cycle's.  Emulated here: every call's batches are solved once OUTSIDE the timed
     # region from start states moved by 1 % of their spread ("the previous cycle"), and the K steps are timed once more
-    # with every call pulling its problems longest-first by those counts (the order argument of alilqr_solve_batches).
+    # with every call pulling its problems longest-first by those counts (alilqr_extras::order passed to alilqr_solve_batches).
     hint = None
     if group > 1 and not args.no_order_hint:
         spread = np.array([0.0, 1.0, 0.2, 0.05]) if n == 4 else np.array([0.0, 1.0, 0.1, 0.0, 1.0, 0.0])

@@ -237,8 +237,12 @@ class MultiBatchSolver:
             if order is not None and (order.dtype != torch.int32 or order.numel() != n * self.desc.batch):
                 raise ValueError("order must be an int32 permutation of the n * batch problems")
             self._order = order                                    # kept alive until the next run
+            ex = None
+            if order is not None:
+                ex = capi.Extras()
+                ex.order = order.data_ptr()
             rc = self.lib.alilqr_solve_batches(C.byref(self.desc), n, L[0], *[_ptr(t) for t in self.shared],
-                                               *L[1:], _ptr(order), C.c_void_p(stream_ptr))
+                                               *L[1:], None if ex is None else C.byref(ex), C.c_void_p(stream_ptr))
         capi.check(rc, "alilqr_solve_batches")
         return self.out
 

@@ -177,7 +177,7 @@ def load_library():
     lib.alilqr_constraints_batch.restype = C.c_int32
     lib.alilqr_constraints_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 13
     lib.alilqr_solve_batches.restype = C.c_int32
-    lib.alilqr_solve_batches.argtypes = [C.POINTER(Problem), C.c_int32] + [C.c_void_p] * 15
+    lib.alilqr_solve_batches.argtypes = [C.POINTER(Problem), C.c_int32] + [C.c_void_p] * 13 + [C.POINTER(Extras), C.c_void_p]
     lib.alilqr_release.restype = C.c_int32
     lib.alilqr_solve_batch_noalloc.restype = C.c_int32
     lib.alilqr_solve_batch_noalloc.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17

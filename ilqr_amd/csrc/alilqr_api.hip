@@ -770,7 +770,7 @@ int32_t alilqr_solve_batches(const alilqr_problem* p, int32_t n_batches,
                              double* const* x_out, double* const* u_out,
                              double* const* node_x, double* const* node_u,
                              double* const* cost, double* const* viol, double* const* mu,
-                             int32_t* const* status, const int32_t* order, void* stream) {
+                             int32_t* const* status, const alilqr_extras* ex, void* stream) {
   if (!p) { set_err("null problem descriptor"); return ALILQR_E_ARG; }
   if (n_batches < 0 || n_batches > 4096) { set_err("n_batches must be 0..4096"); return ALILQR_E_ARG; }
   if (p->goal_batch != 1) { set_err("alilqr_solve_batches takes batches that share one goal list (goal_batch = 1)"); return ALILQR_E_ARG; }
@@ -785,9 +785,8 @@ int32_t alilqr_solve_batches(const alilqr_problem* p, int32_t n_batches,
   alilqr_problem all = *p;
   all.batch = p->batch * n_batches;
   Segments seg{n_batches, p->batch, x0, x_out, u_out, node_x, node_u, cost, viol, mu, status};
-  alilqr_extras ex{};
-  ex.order = order;
-  return solve_impl(&all, nullptr, goals, Q, R, cons, &ex, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+  if (ex && ex->overlay_out) { set_err("overlay_out is not supported by alilqr_solve_batches"); return ALILQR_E_ARG; }
+  return solve_impl(&all, nullptr, goals, Q, R, cons, ex, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                     nullptr, nullptr, nullptr, nullptr, nullptr, stream, false, &seg);
 }
 

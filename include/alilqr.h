@@ -348,8 +348,10 @@ int32_t alilqr_constraints_batch(const alilqr_problem* p,
  * ordinary kernels: while ANOTHER call's solve keeps every SIMD occupied they wait for its waves to finish, so results
  * of overlapping calls become visible late; a latency-sensitive caller keeps one call in flight.  Asynchronous like
  * alilqr_solve_batch: outputs are valid once the stream drains; the pointer lists are read before the call returns.
- *   order  optional DEVICE array [n_batches * B]: a permutation of the problems of all batches (problem b of batch i
- *          is i * B + b) in which they are pulled, see alilqr_extras::order; NULL = as they lie.
+ *   ex     optional inputs as in alilqr_solve_batch_ex (may be NULL), over the problems of all batches in one index
+ *          space (problem b of batch i is i * B + b): order [n_batches * B] (the pull order, see alilqr_extras::order),
+ *          u_offset [n_batches * B][H][m], stop_after, trace_*, mu_solver_*: one contiguous device array each; rectangle
+ *          obstacles and first_row(s) are shared by all problems as always.  overlay_out is not supported here.
  */
 int32_t alilqr_solve_batches(const alilqr_problem* p, int32_t n_batches,
                              const double* const* x0, const double* goals,
@@ -357,7 +359,7 @@ int32_t alilqr_solve_batches(const alilqr_problem* p, int32_t n_batches,
                              double* const* x_out, double* const* u_out,
                              double* const* node_x, double* const* node_u,
                              double* const* cost, double* const* viol, double* const* mu,
-                             int32_t* const* status, const int32_t* order, void* stream);
+                             int32_t* const* status, const alilqr_extras* ex, void* stream);
 
 /* Release every cached device workspace of the calling process (waits for the solves in flight). */
 int32_t alilqr_release(void);

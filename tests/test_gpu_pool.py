@@ -122,3 +122,30 @@ def test_pull_order_hint_changes_nothing_but_the_schedule(tuning):
     for x, y in zip(a, b):
         for k in x:
             assert np.array_equal(x[k], y[k], equal_nan=True), k
+
+
+def test_many_batches_with_optional_inputs_over_the_concatenated_problems():
+    """alilqr_solve_batches with an alilqr_extras: multi-start control offsets (one contiguous array over all batches)
+    and rectangle obstacles (shared) give the bits of alilqr_solve_batch_ex on the concatenated batch."""
+    import ctypes as C
+    import torch
+    prob, kw = problems.new_al_lat_rect(48)
+    desc, x0, goals, Q, R, cons = prob
+    uo = 0.01 * np.random.default_rng(5).standard_normal((48, desc.horizon, desc.m))
+    want = _np(batch.solve_batch(*prob, u_offset=uo, **kw))
+    half = type(desc).from_buffer_copy(desc)
+    half.batch = 24
+    mb = batch.MultiBatchSolver(half, [x0[:24], x0[24:]], goals, Q, R, cons, extras=True)
+    uo_d = torch.as_tensor(uo, device="cuda")
+    lo = torch.as_tensor(capi.pack_rectangles(kw["left_obs"]), device="cuda")
+    ro = torch.as_tensor(capi.pack_rectangles(kw["right_obs"]), device="cuda")
+    ex = capi.Extras(uo_d.data_ptr(), lo.data_ptr(), ro.data_ptr(), len(kw["left_obs"]), len(kw["right_obs"]), kw["first_row"], 0)
+    L = mb._lists
+    P = lambda t: C.c_void_p(t.data_ptr())
+    rc = mb.lib.alilqr_solve_batches(C.byref(half), 2, L[0], *[P(t) for t in mb.shared], *L[1:], C.byref(ex),
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, capi.last_error()
+    torch.cuda.synchronize()
+    for i, o in enumerate(mb.out):
+        for k in o:
+            assert np.array_equal(o[k].cpu().numpy(), want[k][24 * i:24 * (i + 1)], equal_nan=True), (i, k)
