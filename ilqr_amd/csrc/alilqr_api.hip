@@ -680,6 +680,9 @@ static int32_t solve_impl(const alilqr_problem* p,
   // NEW_AL, one linear table for all nodes: the kernel prologue looks for rows without A (B) entries
   ka.sparse_rows = (p->mode == ALILQR_MODE_NEW_AL && p->table_nodes == 1 && !(p->cons_kind & ALILQR_CONS_QUADRATIC) &&
                     p->c <= 64 && !g_opt_dense_rows.load(std::memory_order_relaxed)) ? 1 : 0;
+  // NEW_AL, one table for all nodes: roll-outs skip all-zero rows whose multipliers (and rectangle overlay) are zero
+  ka.live_rows = (p->mode == ALILQR_MODE_NEW_AL && p->table_nodes == 1 && p->c <= 64 &&
+                  !g_opt_dense_rows.load(std::memory_order_relaxed)) ? 1 : 0;
   // The problem counter is never reset: a solve starts from the value the scratch's previous solve left, which
   // the host knows exactly - every problem is pulled once and every group makes one failing pull at the end.
   ka.counter_base = *counter_next;

@@ -75,17 +75,27 @@ inline int launch_family(const KArgs& ka, int G, int waves, hipStream_t st, int 
       return hipGetLastError() == hipSuccess ? LAUNCH_OK : LAUNCH_FAILED;
     }
   }
+  // quadratic tables: the wave stages the tables its roll-outs read (one constraint table, Q, R) in LDS; at most
+  // 64 rows (checked by the C ABI), 24 KB
+  size_t tl = 0;
+  KArgs kt = ka;
+  if constexpr (is_quad(MODE) && ALILQR_TAB_LDS) {
+    using MDx = Model<MODEL>;
+    const size_t cw = (size_t)ka.C * (MDx::N + MDx::M + 1) + (size_t)ka.C * MDx::N * MDx::N;
+    tl = (cw + MDx::N * MDx::N + MDx::M * MDx::M) * sizeof(double);
+    kt.lds_bytes = (int)tl;
+  }
 #ifdef ALILQR_ONLY_G   /* development builds: one lane-group width only (seconds to compile) */
   if (G != ALILQR_ONLY_G) return LAUNCH_BAD_WIDTH;
-  hipLaunchKernelGGL((solve_kernel<MODEL, MODE, ALILQR_ONLY_G>), grid, block, 0, st, ka);
+  hipLaunchKernelGGL((solve_kernel<MODEL, MODE, ALILQR_ONLY_G>), grid, block, tl, st, kt);
   return hipGetLastError() == hipSuccess ? LAUNCH_OK : LAUNCH_FAILED;
 #else
   switch (G) {
-    case 1: hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 1>), grid, block, 0, st, ka); break;
-    case 4: hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 4>), grid, block, 0, st, ka); break;
-    case 8: hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 8>), grid, block, 0, st, ka); break;
-    case 16: hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 16>), grid, block, 0, st, ka); break;
-    case 32: hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32>), grid, block, 0, st, ka); break;
+    case 1: hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 1>), grid, block, tl, st, kt); break;
+    case 4: hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 4>), grid, block, tl, st, kt); break;
+    case 8: hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 8>), grid, block, tl, st, kt); break;
+    case 16: hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 16>), grid, block, tl, st, kt); break;
+    case 32: hipLaunchKernelGGL((solve_kernel<MODEL, MODE, 32>), grid, block, tl, st, kt); break;
     default: return LAUNCH_BAD_WIDTH;
   }
   return hipGetLastError() == hipSuccess ? LAUNCH_OK : LAUNCH_FAILED;

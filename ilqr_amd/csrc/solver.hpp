@@ -71,6 +71,34 @@ __device__ __forceinline__ ctab as_ctab(const double* p) {
   return (ctab)p;
 #pragma clang diagnostic pop
 }
+// The same tables staged in LDS (read by every lane at one address: a broadcast, no bank conflict).
+typedef const double __attribute__((address_space(3)))* ltab;
+__device__ __forceinline__ ltab as_ltab(const double* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (ltab)p;
+#pragma clang diagnostic pop
+}
+#ifndef ALILQR_TAB_LDS
+#define ALILQR_TAB_LDS 1
+#endif
+// a value that is the same in every lane, as a scalar (host builds: the value)
+__device__ __forceinline__ unsigned long long wave_uniform(unsigned long long m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)m), hi = __builtin_amdgcn_readfirstlane((unsigned int)(m >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+#else
+  return m;
+#endif
+}
+// orders the LDS writes of a wave's lanes before the LDS reads of its other lanes (one wave per block)
+__device__ __forceinline__ void wave_lds_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
 
 // Cold kernel arguments.  solve_kernel takes one argument block (KArgs) of ~60 scalar registers' worth of pointers and
 // constants.  A field that is named as a.field is loaded once at kernel entry and then held for the whole solve - or,
@@ -175,6 +203,8 @@ struct KArgs {
   unsigned long long quad_rows;   // rows whose quadratic matrix is not all zero, over all tables (kernel prologue)
   int sparse_rows;            // host: the one shared linear table may be searched for all-zero A / B rows
   unsigned long long azero, bzero;   // NEW_AL: rows whose A (B) entries are all zero (kernel prologue; 0 = none known)
+  int live_rows;              // host: roll-outs may skip rows that cannot contribute (all-zero table row, zero multiplier)
+  unsigned long long zrows;   // NEW_AL: rows of the shared table that are all zero (kernel prologue; 0 = none known)
   ModelConst mc;
   alilqr_params prm;
   const double *x0, *goals, *Q, *R, *cons;
@@ -782,9 +812,10 @@ struct NewAlOps {
   static constexpr int N = MD::N, M = MD::M;
 
   // x' Qc_i x as (x' Qc_i) x  (quadratic_constraints.h:21-24); rows with an all-zero matrix are skipped (exact zero)
-  __device__ static __forceinline__ double quad_term(const KArgs& a, ctab tab, const double* x, int i) {
+  template <class TP>
+  __device__ static __forceinline__ double quad_term(const KArgs& a, TP tab, const double* x, int i) {
     if (!QUAD || !((a.quad_rows >> i) & 1ull)) return 0.0;
-    ctab Qi = tab + a.C * (N + M + 1) + (size_t)i * N * N;
+    TP Qi = tab + a.C * (N + M + 1) + (size_t)i * N * N;
     double q = 0.0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -843,14 +874,41 @@ struct NewAlOps {
         if (i0 + q < a.C) f(i0 + q, r[q]);
     }
   }
+  // The rows of the bit mask `m` (uniform over the wave) in order.  The roll-outs skip rows that cannot contribute: a row
+  // whose table entries are all zero, whose rectangle overlay is empty and whose multiplier is zero adds
+  // (min(0 - mu * 0, 0))^2 = +0 to one sum and 0^2 = +0 to the other at a finite point - no bit of the cost changes.
+  template <class F>
+  __device__ static __forceinline__ void for_live(const KArgs& a, const double* lam, size_t ls, unsigned long long m, F&& f) {
+    while (m != 0ull) {
+      const int i = __builtin_ctzll(m);
+      m &= m - 1ull;
+      Row r;
+      r.l = lam[(size_t)i * ls];
+      r.sgn = RECT ? lam[(size_t)(a.C + i) * ls] : 0.0;
+      r.cn = RECT ? lam[(size_t)(2 * a.C + i) * ls] : 0.0;
+      f(i, r);
+    }
+  }
+  // mask of the rows a roll-out step evaluates: `live` unless a lane of the wave holds a non-finite point (0 * inf is
+  // a NaN in the dense sums of every row, so every row counts then)
+  __device__ static __forceinline__ unsigned long long step_rows(const KArgs& a, unsigned long long live, bool box,
+                                                                 const double* x, const double* u) {
+    unsigned long long m = live;
+    if (m != ~0ull && __any(!all_finite<N, M>(x, u))) m = ~0ull;
+    if (a.C < 64) m &= (1ull << a.C) - 1ull;
+    if (box) m &= ~((1ull << NBOX) - 1ull);
+    return wave_uniform(m);
+  }
   // the row-loaded forms of a_ij / c_i / cval / par_cval (same arithmetic)
-  __device__ static __forceinline__ double a_ij(ctab A, const Row& r, int i, int j) {
+  template <class TP>
+  __device__ static __forceinline__ double a_ij(TP A, const Row& r, int i, int j) {
     if (RECT) {
       if (r.sgn != 0.0) return (j == 1) ? r.sgn : 0.0;
     }
     return A[i * N + j];
   }
-  __device__ static __forceinline__ double c_i(ctab Cv, const Row& r, int i) {
+  template <class TP>
+  __device__ static __forceinline__ double c_i(TP Cv, const Row& r, int i) {
     if (RECT) {
       if (r.sgn != 0.0) return r.cn;
     }
@@ -882,30 +940,34 @@ struct NewAlOps {
   static constexpr bool SPARSE = !QUAD && N > 4;
   __device__ static __forceinline__ bool a_zero(const KArgs& a, int i) { return SPARSE && ((a.azero >> i) & 1ull) != 0ull; }
   __device__ static __forceinline__ bool b_zero(const KArgs& a, int i) { return SPARSE && ((a.bzero >> i) & 1ull) != 0ull; }
-  __device__ static __forceinline__ double ax_of(const KArgs& a, ctab A, const double* x, int i, const Row& r, const ZeroSums& z) {
+  template <class TP>
+  __device__ static __forceinline__ double ax_of(const KArgs& a, TP A, const double* x, int i, const Row& r, const ZeroSums& z) {
     if (a_zero(a, i)) return RECT ? (0.0 + r.sgn * x[1]) + z.x1 : z.xa;
     double ax = 0.0;
 #pragma unroll
     for (int j = 0; j < N; ++j) ax += a_ij(A, r, i, j) * x[j];
     return ax;
   }
-  __device__ static __forceinline__ double bu_of(const KArgs& a, ctab Bm, const double* u, int i, const ZeroSums& z) {
+  template <class TP>
+  __device__ static __forceinline__ double bu_of(const KArgs& a, TP Bm, const double* u, int i, const ZeroSums& z) {
     if (b_zero(a, i)) return z.ub;
     double bu = 0.0;
 #pragma unroll
     for (int j = 0; j < M; ++j) bu += Bm[i * M + j] * u[j];
     return bu;
   }
-  __device__ static __forceinline__ double cval(const KArgs& a, ctab tab, const double* x, const double* u, int i, const Row& r,
+  template <class TP>
+  __device__ static __forceinline__ double cval(const KArgs& a, TP tab, const double* x, const double* u, int i, const Row& r,
                                                 const ZeroSums& z) {
-    ctab A = tab, Bm = tab + a.C * N, Cv = tab + a.C * (N + M);
+    TP A = tab, Bm = tab + a.C * N, Cv = tab + a.C * (N + M);
     const double ax = ax_of(a, A, x, i, r, z), bu = bu_of(a, Bm, u, i, z);
     if (QUAD) return ((quad_term(a, tab, x, i) + ax) + bu) + c_i(Cv, r, i);
     return ax + bu + c_i(Cv, r, i);
   }
-  __device__ static __forceinline__ double par_cval(const KArgs& a, ctab tab, const double* x, const double* u, int i, const Row& r,
+  template <class TP>
+  __device__ static __forceinline__ double par_cval(const KArgs& a, TP tab, const double* x, const double* u, int i, const Row& r,
                                                     const ZeroSums& z) {
-    ctab Cv = tab + a.C * (N + M);
+    TP Cv = tab + a.C * (N + M);
     const double ax = ax_of(a, tab, x, i, r, z), bu = bu_of(a, tab + a.C * N, u, i, z);
     double c = ax + bu + c_i(Cv, r, i);
     if (QUAD) c = c + quad_term(a, tab, x, i);
@@ -936,9 +998,10 @@ struct NewAlOps {
     if (QUAD) c = c + quad_term(a, tab, x, i);
     return c;
   }
-  __device__ static double cost(const KArgs& a, ctab Q, ctab R, ctab tab,
+  template <bool LIVE = false, class TP>
+  __device__ static double cost(const KArgs& a, TP Q, TP R, TP tab,
                                 const double* x, const double* u, const double* g,
-                                const double* lam, size_t ls, double mu) {
+                                const double* lam, size_t ls, double mu, unsigned long long live = ~0ull) {
     double sc = 0.0, cc = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) { double e = x[i] - g[i]; sc += (e * Q[i * N + i]) * e; }
@@ -947,7 +1010,7 @@ struct NewAlOps {
     double pp = 0.0, ll = 0.0;
     const bool box = boxed(a, x, u);
     if (box) {
-      ctab Cv = tab + a.C * (N + M);
+      TP Cv = tab + a.C * (N + M);
 #pragma unroll
       for (int i = 0; i < NBOX; ++i) {
         const BoxRow<N, M> row{i};
@@ -959,19 +1022,22 @@ struct NewAlOps {
       }
     }
     const ZeroSums zs = zero_sums(x, u);
-    for_rows(a, lam, ls, [&](int i, const Row& r) {
+    auto row = [&](int i, const Row& r) {
       const double l = r.l;
       const double f = l - mu * cval(a, tab, x, u, i, r, zs);
       double lp = a.eq ? f : fmin(f, 0.0);          // constraints.h:520-528
       pp += lp * lp;
       ll += l * l;
-    }, box ? NBOX : 0);
+    };
+    if constexpr (LIVE) for_live(a, lam, ls, step_rows(a, live, box, x, u), row);
+    else for_rows(a, lam, ls, row, box ? NBOX : 0);
     return sc + cc + 0.5 / mu * (pp - ll);
   }
   // one column of parallel_cost / parallel_augmented_lagrangian_cost (constraints.h:558-580)
-  __device__ static double par_cost(const KArgs& a, ctab Q, ctab R, ctab tab,
+  template <bool LIVE = false, class TP>
+  __device__ static double par_cost(const KArgs& a, TP Q, TP R, TP tab,
                                     const double* x, const double* u, const double* g,
-                                    const double* lam, size_t ls, double mu) {
+                                    const double* lam, size_t ls, double mu, unsigned long long live = ~0ull) {
     double cq = 0.0, cr = 0.0, al = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) { double e = x[i] - g[i]; cq += e * (e * Q[i * N + i]); }
@@ -979,7 +1045,7 @@ struct NewAlOps {
     for (int j = 0; j < M; ++j) cr += (R[j * M + j] * u[j]) * u[j];
     const bool box = boxed(a, x, u);
     if (box) {
-      ctab Cv = tab + a.C * (N + M);
+      TP Cv = tab + a.C * (N + M);
 #pragma unroll
       for (int i = 0; i < NBOX; ++i) {
         const BoxRow<N, M> row{i};
@@ -990,12 +1056,14 @@ struct NewAlOps {
       }
     }
     const ZeroSums zs = zero_sums(x, u);
-    for_rows(a, lam, ls, [&](int i, const Row& r) {
+    auto row = [&](int i, const Row& r) {
       const double l = r.l;
       const double f = l - mu * par_cval(a, tab, x, u, i, r, zs);
       double pr = a.eq ? f : fmin(f, 0.0);
       al += pr * pr - l * l;
-    }, box ? NBOX : 0);
+    };
+    if constexpr (LIVE) for_live(a, lam, ls, step_rows(a, live, box, x, u), row);
+    else for_rows(a, lam, ls, row, box ? NBOX : 0);
     al = 0.5 / mu * al;
     return (cq + cr) + al;
   }
@@ -1312,6 +1380,17 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           if (nz) a.quad_rows |= 1ull << i;
         }
     }
+    // which rows of the shared table are all zero (A, B, C and the quadratic term)
+    a.zrows = 0ull;
+    if (is_new_al(MODE) && a.live_rows && a.table_nodes == 1) {
+      ctab ct = as_ctab(a.cons);
+      for (int i = 0; i < C && i < 64; ++i) {
+        bool z = (ct[C * (N + M) + i] == 0.0) && !(QUAD && ((a.quad_rows >> i) & 1ull));
+        for (int j = 0; j < N; ++j) z &= (ct[i * N + j] == 0.0);
+        for (int j = 0; j < M; ++j) z &= (ct[C * N + i * M + j] == 0.0);
+        if (z) a.zrows |= 1ull << i;
+      }
+    }
     // which rows of the shared linear table have no A (no B) entry
     a.azero = 0ull; a.bzero = 0ull;
     if (is_new_al(MODE) && !QUAD && a.sparse_rows && a.table_nodes == 1 && a.C <= 64) {
@@ -1396,6 +1475,27 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   auto tabR = [&](int t) { return as_ctab(a.R) + (size_t)tnode(t) * M * M; };
   auto tabC = [&](int t) { return as_ctab(a.cons) + (size_t)tnode(t) * cw; };
 #endif
+  // NEW_AL: the tables the roll-outs read (constraint table, Q, R) are staged in LDS.  A roll-out step evaluates the
+  // rows of a node one after the other; with the table behind scalar loads every row waits for two round trips to the
+  // scalar cache, with the table in LDS the reads are issued rows ahead and return in order.  A table shared by all
+  // nodes is staged once per kernel; per-node tables are staged node by node inside the roll-out.
+  constexpr bool TLDS = QUAD && (ALILQR_TAB_LDS != 0);
+  // Roll-outs skip rows that cannot contribute (below).  Measured on 4096 problems: lateral model with the reference's
+  // ten-row table (two live rows) 73 -> 101 k solves/s, with rectangle rows 41 -> 51 k; 6-state tables with two to four
+  // spare rows unchanged; quadratic tables (every row live) lose a third with the masked loop and keep the plain one.
+  constexpr bool LIVE = NEWAL && !QUAD;
+  const ltab ltC = as_ltab(lds_pool), ltQ = ltC + cw, ltR = ltQ + N * N;
+  auto stage_tables = [&](int t) {           // every active lane writes the same values
+    if constexpr (TLDS) {
+      (void)ALILQR_CHK((size_t)(cw + N * N + M * M) * sizeof(double) <= (size_t)a.lds_bytes, 16);
+      ctab sc = tabC(t), sq = tabQ(t), sr = tabR(t);
+      for (int k = 0; k < cw; ++k) lds_pool[k] = sc[k];
+      for (int k = 0; k < N * N; ++k) lds_pool[cw + k] = sq[k];
+      for (int k = 0; k < M * M; ++k) lds_pool[cw + N * N + k] = sr[k];
+      wave_lds_fence();
+    }
+  };
+  if (TLDS && a.table_nodes <= 1) stage_tables(0);
 
   // goal list of problem q (clamped: idle groups still form addresses)
   auto goal_of = [&](int q) -> const double* {
@@ -1894,6 +1994,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
       // C++ generation: u + (K dx + alpha k)); kind 1: LEGACY open loop on the accumulated controls of
       // lane `ul`; kind 2: one column of the C++ generation's five-wide ladder (no angle wrap, (u + K dx) + k alpha)
       // fly2 (accumulated controls in LDS): the lane runs trial 2, whose controls u + k / 2 are formed from the record
+      unsigned long long live_rows = ~0ull;  // NEW_AL: the rows the roll-outs of this pass evaluate (found before the pass)
       auto rollout = [&](const Tgt& tg, bool valid, int kind, double alpha, const double* ucol, size_t ucs, int sslot, bool fly2 = false) -> double {
         double J = 0.0;
         double x[N];
@@ -1918,8 +2019,13 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         double uown[M];
 #pragma unroll
         for (int r = 0; r < M; ++r) uown[r] = (LEGACY && kind == 1 && valid && !(LDSUC && fly2)) ? ucol[(size_t)r * ucs] : 0.0;
+        // tables of node t as the roll-out reads them
+        auto rQ = [&](int t) { if constexpr (TLDS) { (void)t; return ltQ; } else return tabQ(t); };
+        auto rR = [&](int t) { if constexpr (TLDS) { (void)t; return ltR; } else return tabR(t); };
+        auto rC = [&](int t) { if constexpr (TLDS) { (void)t; return ltC; } else return tabC(t); };
         auto roll = [&](int t, const RecRegs& R, RecRegs& Rn) {
           load_rec(tg, t + 1, Rn, closed);             // next record in flight while this step computes
+          if (TLDS && a.table_nodes > 1) stage_tables(t);
           double unext[M];
 #pragma unroll
           for (int r = 0; r < M; ++r)
@@ -1961,11 +2067,11 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
             if constexpr (NEWAL) {
               const double* lp = rec(t) + (size_t)RL::rl * ES;
               if (kind == 2) {
-                J += OPS::par_cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, lp, ES, mu);
+                J += OPS::template par_cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
                 keep();
                 MD::par_step(mc, x, u, xn);
               } else {
-                J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, lp, ES, mu);
+                J += OPS::template cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
                 keep();
                 MD::template step<false>(mc, x, u, xn);
               }
@@ -2005,8 +2111,9 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           for (int r = 0; r < M; ++r) zu[r] = 0.0;
           if constexpr (NEWAL) {
             const double* lp = rec(H) + (size_t)RL::rl * ES;
-            if (kind == 2) J += OPS::par_cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, lp, ES, mu);
-            else J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, lp, ES, mu);
+            if (TLDS && a.table_nodes > 1) stage_tables(H);
+            if (kind == 2) J += OPS::template par_cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
+            else J += OPS::template cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
           } else {
             if (LEGACY) J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, RA.lam, 1, mu);
             else J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, rec(H) + (size_t)RL::rl * ES, ES, mu);
@@ -2209,6 +2316,30 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           if (LEGACY) uct = (win_trial >= 2) ? win_trial : 2;
         }
         __threadfence_block();
+        if constexpr (LIVE) {
+          // Rows with an all-zero table row count only at nodes where their multiplier or their rectangle overlay is
+          // not zero: the lanes of each group look through the group's nodes, a row that is live in any group rolling
+          // out in this pass is evaluated by the whole wave (evaluating a dead row changes nothing).
+          live_rows = ~0ull;
+          const unsigned long long zr = a.zrows;
+          if (zr != 0ull) {
+            unsigned long long lm = 0ull;
+            for (int t = gl; t <= H; t += G) {
+              const double* lp = rec(t) + (size_t)RL::rl * ES;
+              for (unsigned long long z = zr; z != 0ull; z &= z - 1ull) {
+                const int i = __builtin_ctzll(z);
+                bool nz = lp[(size_t)i * ES] != 0.0;
+                if (RECT) nz = nz || (lp[(size_t)(C + i) * ES] != 0.0);
+                if (nz) lm |= 1ull << i;
+              }
+            }
+            live_rows = ~zr;
+            for (unsigned long long z = zr; z != 0ull; z &= z - 1ull) {
+              const int i = __builtin_ctzll(z);
+              if (__ballot(((lm >> i) & 1ull) != 0ull) != 0ull) live_rows |= 1ull << i;
+            }
+          }
+        }
         const double J = rollout(own, valid, kind, alpha, LEGACY ? ucgr + (uct - 2) : nullptr, UCSr, sslot);
 
         if (stage == ST_TRIALS) {

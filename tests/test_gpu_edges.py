@@ -96,6 +96,47 @@ def test_per_node_tables(mode):
     assert np.abs(shared["x"] - o["x"]).max() > 1e-3    # the per-node tables were used
 
 
+def test_per_node_quadratic_tables():
+    """table_nodes = H + 1 with quadratic rows: the circle's radius grows along the horizon, the terminal weight is ten
+    times larger.  (The roll-outs read quadratic tables from LDS; per-node tables are staged there node by node.)"""
+    H, B = 30, 12
+    desc, x0, goals, Q, R, cons = problems.new_al_lat_circle(B, H, seed=28)
+    c, n, m = desc.c, desc.n, desc.m
+    d = type(desc).from_buffer_copy(desc); d.table_nodes = H + 1
+    Qn = np.tile(Q, (H + 1, 1, 1)); Qn[H] *= 10.0
+    Rn = np.tile(R, (H + 1, 1, 1))
+    Cn = np.tile(cons, (H + 1, 1))
+    for t in range(H + 1):
+        r = 6.0 + 0.05 * t
+        Qc, A, C0 = problems.circle_rows(30.0, 11.0, r, n)
+        Cn[t, :n] = A
+        Cn[t, c * (n + m)] = C0
+        Cn[t, c * (n + m + 1): c * (n + m + 1) + n * n] = Qc.ravel()
+    # these solves are sensitive to rounding by their end (few reproduce under a 1e-13 move of the start state): the
+    # first iterations are compared on every problem, the end of the solve where the oracle reproduces itself
+    for k in (3, 12):
+        check((d, x0, goals, Qn, Rn, Cn), floor=0.75, label=f"edges/per-node quadratic tables, iteration {k}", stop_after=k)
+    o, ref = check((d, x0, goals, Qn, Rn, Cn), floor=0.0, label="edges/per-node quadratic tables")
+    shared = to_np(batch.solve_batch(desc, x0, goals, Q, R, cons))
+    assert np.abs(shared["x"] - o["x"]).max() > 1e-3    # the per-node tables were used
+
+
+def test_row_without_coefficients_but_with_a_constant_counts():
+    """The roll-outs skip table rows that are all zero while their multipliers are zero (they add nothing to the cost).
+    Row 5 of the reference's ten-row table becomes  0 x + 0 u + 0.002 <= 0  here: no A or B entry, but always violated
+    (by less than the bound under which multipliers are updated) - it is not a row of zeros and its multiplier grows.  (Rows of zeros that the rectangle activation
+    fills later are covered by the rectangle sets of the golden and configuration tests.)"""
+    H, B = 30, 12
+    desc, x0, goals, Q, R, cons = problems.new_al_lat(B, H, seed=29)
+    c, n, m = desc.c, desc.n, desc.m
+    one = np.array(cons, copy=True)
+    one[c * (n + m) + 5] = 0.002
+    o, ref = check((desc, x0, goals, Q, R, one), floor=0.3, label="edges/violated row of zeros")
+    assert (o["lam"][:, :, 5] != 0).any()
+    plain = to_np(batch.solve_batch(desc, x0, goals, Q, R, cons))
+    assert np.abs(plain["cost"] - o["cost"]).max() > 1e-6
+
+
 @pytest.mark.parametrize("name", ["legacy_lat", "new_al_lat4", "fast_box"])
 def test_long_horizon(name):
     """H = 200: the linearisation records of a group no longer fit the LDS share of its wave, every record lives in HBM."""

@@ -33,7 +33,8 @@ def main():
                  "dyn_legacy_h100": lambda: problems.full_legacy("dyn", B, 100, 2),
                  "fast_box": lambda: problems.fast_box(B), "new_al_box6": lambda: problems.new_al_box(B),
                  "fast_box_linear_h100": lambda: problems.fast_box_linear(B), "kin_rect": lambda: problems.kin_rect(B),
-                 "new_al_circle6": lambda: problems.new_al_circle(B), "kin_linear": lambda: problems.kin_linear(B)}
+                 "new_al_circle6": lambda: problems.new_al_circle(B), "kin_linear": lambda: problems.kin_linear(B),
+                 "new_al_lat4": lambda: problems.new_al_lat(B)}
     wl = os.environ.get("WORKLOAD", "lat_legacy")
     prob, kw = workloads[wl](), {}
     if isinstance(prob[0], tuple):
