@@ -1067,10 +1067,11 @@ struct NewAlOps {
     al = 0.5 / mu * al;
     return (cq + cr) + al;
   }
+  template <bool LIVE = false>
   __device__ static void quadratize(const KArgs& a, ctab Q, ctab R, ctab tab,
                                     const double* x, const double* u, const double* g,
                                     const double* lam, size_t ls, double mu,
-                                    double* rec, size_t rs) {
+                                    double* rec, size_t rs, unsigned long long live = ~0ull) {
     using LL = LinLayout<MD>;
     ctab A = tab, Bm = tab + a.C * N;
     double e[N], jx[N], ju[M], hx[N][N], hu[M][M], tq[N][N];
@@ -1109,7 +1110,9 @@ struct NewAlOps {
       }
     }
     const ZeroSums zs = zero_sums(x, u);
-    for_rows(a, lam, ls, [&](int i, const Row& r) {
+    // (a skipped row - all-zero table row, zero multiplier, finite point - has lp = +-0 and coefficients 0: every term it
+    //  adds below is +-0, and a sum that started at +0 keeps its bits)
+    auto row = [&](int i, const Row& r) {
       const double fi = r.l - mu * cval(a, tab, x, u, i, r, zs);
       double lp = a.eq ? fi : fmin(fi, 0.0);        // the equality branch works on the factor itself (constraints.h:673-676)
       double on = a.eq ? 1.0 : ((lp >= 0.0) ? 0.0 : 1.0);
@@ -1173,7 +1176,9 @@ struct NewAlOps {
       for (int p = 0; p < M; ++p)
 #pragma unroll
         for (int q = 0; q < M; ++q) hu[p][q] += a.eq ? (Bm[i * M + p] * Bm[i * M + q]) : ((mu * pb[p]) * Bm[i * M + q]);
-    }, box ? NBOX : 0);
+    };
+    if constexpr (LIVE) for_live(a, lam, ls, step_rows(a, live, box, x, u), row);
+    else for_rows(a, lam, ls, row, box ? NBOX : 0);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       double s = 0.0;
@@ -1193,25 +1198,38 @@ struct NewAlOps {
       for (int j = 0; j < M; ++j) rec[(LL::oLuu + i * M + j) * rs] = 2 * R[i * M + j] + (a.eq ? mu * hu[i][j] : hu[i][j]);
     }
   }
+  // (a skipped row has c = +0: it neither raises the violation nor moves its multiplier off zero)
+  template <bool LIVE = false>
   __device__ static double violation(const KArgs& a, ctab tab, const double* x, const double* u,
-                                     const double* lam, size_t ls, double mu) {
+                                     const double* lam, size_t ls, double mu, unsigned long long live = ~0ull) {
     double v = 0.0;
-    for (int i = 0; i < a.C; ++i) {
+    auto row = [&](int i) {
       double c = cval(a, tab, x, u, i, lam, ls);
       double dc = fabs(c - fmin(c, 0.0));
       v = (dc > v) ? dc : v;
+    };
+    if constexpr (LIVE) {
+      for (unsigned long long m = step_rows(a, live, false, x, u); m != 0ull; m &= m - 1ull) row(__builtin_ctzll(m));
+    } else {
+      for (int i = 0; i < a.C; ++i) row(i);
     }
     (void)mu;
     return v;
   }
   __device__ static double combine_violation(double acc, double node) { return (node > acc) ? node : acc; }
   __device__ static double violation_init() { return -1.0; }
+  template <bool LIVE = false>
   __device__ static void update_lambda(const KArgs& a, ctab tab, const double* x, const double* u,
-                                       double* lam, size_t ls, double mu) {
-    for (int i = 0; i < a.C; ++i) {
+                                       double* lam, size_t ls, double mu, unsigned long long live = ~0ull) {
+    auto row = [&](int i) {
       double c = cval(a, tab, x, u, i, lam, ls);
       const double f = lam[i * ls] - mu * c;
       lam[i * ls] = a.eq ? f : fmin(f, 0.0);        // constraints.h:878-887
+    };
+    if constexpr (LIVE) {
+      for (unsigned long long m = step_rows(a, live, false, x, u); m != 0ull; m &= m - 1ull) row(__builtin_ctzll(m));
+    } else {
+      for (int i = 0; i < a.C; ++i) row(i);
     }
   }
 };
@@ -1510,6 +1528,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
     for (int j = 0; j < M; ++j) u[j] = (t < H) ? *trj_at(cur_par, XS + t * M + j, cur_slot) : 0.0;
   };
   // cost of node t at (x,u) with the node's goal and multipliers read from its record
+  unsigned long long live_now = ~0ull;       // NEW_AL: the rows node_cost evaluates (set per trip of the wave loop, see live_rows)
   auto node_cost = [&](int t, const double* x, const double* u) -> double {
     const double* r = rec(t);
     double g[N];
@@ -1521,7 +1540,8 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
       for (int i = 0; i < CL; ++i) lam[i] = r[(size_t)(RL::rl + i) * ES];
       return OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, g, lam, 1, mu);
     }
-    return OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, g, r + (size_t)RL::rl * ES, ES, mu);
+    if constexpr (LIVE) return OPS::template cost<true>(a, tabQ(t), tabR(t), tabC(t), x, u, g, r + (size_t)RL::rl * ES, ES, mu, live_now);
+    else return OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, g, r + (size_t)RL::rl * ES, ES, mu);
   };
 
   // total cost of the current trajectory: node costs in parallel, summed in node order (ilqr.py:52-56)
@@ -1714,11 +1734,9 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
     // every group of the wave idle and nothing left to pull: done
     if (__ballot(p >= 0) == 0ull) break;
 
-    if (p >= 0 && phase == PH_LIN) {
-     {
-      // ================= outer-iteration start: J under the current multipliers =================
-      bool tables_changed = false;
-      if (RECT) {
+    bool tables_changed = false;
+    if (RECT && p >= 0 && phase == PH_LIN) {
+      {
         // ---- row activation (new_al_ilqr.h:525-625): nodes in parallel; a node inside a rectangle gets the
         //      rectangle's y-bound written into the next row of its own table
         bool mine = false;
@@ -1766,6 +1784,40 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         tables_changed = gfirst<G>(mine, lane) >= 0;
         __threadfence_block();
       }
+    }
+    // NEW_AL: the rows this trip of the loop evaluates.  A row of the shared table that is all zero counts only at nodes
+    // where its multiplier or its rectangle overlay is not zero (NodeOps::for_live): the lanes of each group look through
+    // the group's nodes, and a row that is live in any group of the wave is evaluated by the whole wave (evaluating a
+    // dead row changes nothing).  Dead rows stay dead until the next row activation: their c is +0, so the multiplier
+    // update leaves a zero multiplier at zero.
+    unsigned long long live_rows = ~0ull;
+    if constexpr (LIVE) {
+      const unsigned long long zr = a.zrows;
+      if (zr != 0ull) {
+        unsigned long long lm = 0ull;
+        if (p >= 0) {
+          for (int t = gl; t <= H; t += G) {
+            const double* lp = rec(t) + (size_t)RL::rl * ES;
+            for (unsigned long long z = zr; z != 0ull; z &= z - 1ull) {
+              const int i = __builtin_ctzll(z);
+              bool nz = lp[(size_t)i * ES] != 0.0;
+              if (RECT) nz = nz || (lp[(size_t)(C + i) * ES] != 0.0);
+              if (nz) lm |= 1ull << i;
+            }
+          }
+        }
+        live_rows = ~zr;
+        for (unsigned long long z = zr; z != 0ull; z &= z - 1ull) {
+          const int i = __builtin_ctzll(z);
+          if (__ballot(((lm >> i) & 1ull) != 0ull) != 0ull) live_rows |= 1ull << i;
+        }
+      }
+    }
+    live_now = live_rows;
+
+    if (p >= 0 && phase == PH_LIN) {
+     {
+      // ================= outer-iteration start: J under the current multipliers =================
       if (outer_start || tables_changed) {
         // J of the current trajectory under the current multipliers and tables (what CalcDerivatives leaves in cost_list_)
         old_cost = total_cost();
@@ -1824,7 +1876,8 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
             for (int i = 0; i < M; ++i) lr[(size_t)(NR::oHu + i) * ES] = q[LL::oLuu + i * M + i];
           }
         } else {
-          OPS::quadratize(a, tabQ(t), tabR(t), tabC(t), x, u, g, r + (size_t)RL::rl * ES, ES, mu, q, 1);
+          if constexpr (LIVE) OPS::template quadratize<true>(a, tabQ(t), tabR(t), tabC(t), x, u, g, r + (size_t)RL::rl * ES, ES, mu, q, 1, live_rows);
+          else OPS::quadratize(a, tabQ(t), tabR(t), tabC(t), x, u, g, r + (size_t)RL::rl * ES, ES, mu, q, 1);
 #pragma unroll
           for (int i = 0; i < N * N; ++i) lr[(size_t)(NR::oHx + i) * ES] = q[LL::oLxx + i];
 #pragma unroll
@@ -1994,7 +2047,6 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
       // C++ generation: u + (K dx + alpha k)); kind 1: LEGACY open loop on the accumulated controls of
       // lane `ul`; kind 2: one column of the C++ generation's five-wide ladder (no angle wrap, (u + K dx) + k alpha)
       // fly2 (accumulated controls in LDS): the lane runs trial 2, whose controls u + k / 2 are formed from the record
-      unsigned long long live_rows = ~0ull;  // NEW_AL: the rows the roll-outs of this pass evaluate (found before the pass)
       auto rollout = [&](const Tgt& tg, bool valid, int kind, double alpha, const double* ucol, size_t ucs, int sslot, bool fly2 = false) -> double {
         double J = 0.0;
         double x[N];
@@ -2316,30 +2368,6 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           if (LEGACY) uct = (win_trial >= 2) ? win_trial : 2;
         }
         __threadfence_block();
-        if constexpr (LIVE) {
-          // Rows with an all-zero table row count only at nodes where their multiplier or their rectangle overlay is
-          // not zero: the lanes of each group look through the group's nodes, a row that is live in any group rolling
-          // out in this pass is evaluated by the whole wave (evaluating a dead row changes nothing).
-          live_rows = ~0ull;
-          const unsigned long long zr = a.zrows;
-          if (zr != 0ull) {
-            unsigned long long lm = 0ull;
-            for (int t = gl; t <= H; t += G) {
-              const double* lp = rec(t) + (size_t)RL::rl * ES;
-              for (unsigned long long z = zr; z != 0ull; z &= z - 1ull) {
-                const int i = __builtin_ctzll(z);
-                bool nz = lp[(size_t)i * ES] != 0.0;
-                if (RECT) nz = nz || (lp[(size_t)(C + i) * ES] != 0.0);
-                if (nz) lm |= 1ull << i;
-              }
-            }
-            live_rows = ~zr;
-            for (unsigned long long z = zr; z != 0ull; z &= z - 1ull) {
-              const int i = __builtin_ctzll(z);
-              if (__ballot(((lm >> i) & 1ull) != 0ull) != 0ull) live_rows |= 1ull << i;
-            }
-          }
-        }
         const double J = rollout(own, valid, kind, alpha, LEGACY ? ucgr + (uct - 2) : nullptr, UCSr, sslot);
 
         if (stage == ST_TRIALS) {
@@ -2476,7 +2504,8 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
               for (int i = 0; i < CL; ++i) lam[i] = rec(t)[(size_t)(RL::rl + i) * ES];
               vt = OPS::violation(a, tabC(t), x, u, lam, 1, mu);
             } else {
-              vt = OPS::violation(a, tabC(t), x, u, rec(t) + (size_t)RL::rl * ES, ES, mu);
+              if constexpr (LIVE) vt = OPS::template violation<true>(a, tabC(t), x, u, rec(t) + (size_t)RL::rl * ES, ES, mu, live_rows);
+              else vt = OPS::violation(a, tabC(t), x, u, rec(t) + (size_t)RL::rl * ES, ES, mu);
             }
           }
           for (int g = 0; g < G && t0 + g <= H; ++g) vtot = OPS::combine_violation(vtot, gbcast<G>(vt, g));
@@ -2497,7 +2526,8 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
                 double x[N], u[M];
                 load_node(t, x, u);
                 double* lp = rec(t) + (size_t)RL::rl * ES;
-                OPS::update_lambda(a, tabC(t), x, u, lp, ES, mu);
+                if constexpr (LIVE) OPS::template update_lambda<true>(a, tabC(t), x, u, lp, ES, mu, live_rows);
+                else OPS::update_lambda(a, tabC(t), x, u, lp, ES, mu);
                 if (LEGACY) {
 #pragma unroll
                   for (int i = 0; i < CL; ++i) nz |= (lp[(size_t)i * ES] != 0.0);
