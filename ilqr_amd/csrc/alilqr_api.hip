@@ -270,7 +270,9 @@ Plan make_plan(const alilqr_problem* p, const Dims& d, bool rect = false, size_t
   if (waves < 1) waves = 1;
   const size_t H = p->horizon, N = d.N, M = d.M;
   const size_t T = (H + 1) * N + H * M;
-  const size_t SS = (p->mode == ALILQR_MODE_LEGACY) ? alilqr::TrjSlots<ALILQR_MODE_LEGACY>::SS : alilqr::TrjSlots<ALILQR_MODE_FAST>::SS;
+  const size_t SS = (p->mode == ALILQR_MODE_LEGACY) ? alilqr::TrjSlots<ALILQR_MODE_LEGACY, 4>::SS
+                  : (p->mode == ALILQR_MODE_FAST) ? alilqr::TrjSlots<ALILQR_MODE_FAST, 6>::SS
+                  : (d.N <= 4) ? alilqr::TrjSlots<ALILQR_MODE_NEW_AL, 4>::SS : alilqr::TrjSlots<ALILQR_MODE_NEW_AL, 6>::SS;
   // LEGACY: one column of accumulated controls per open-loop line-search trial (2 .. ntrials; the kernel counts
   // its trials the same way: alpha = 1, 1/2, ... while alpha > alpha_min, at most 64)
   size_t ucols = 0;
@@ -903,12 +905,12 @@ int32_t alilqr_debug_read(unsigned* out) {
 #endif
 
 #ifdef ALILQR_PROF
-/* profiling builds only: copy the 9 phase counters of the last solve on this device to the host */
+/* profiling builds only: copy the 9 phase counters and the 2 roll-out counters of the last solve on this device to the host */
 int32_t alilqr_prof_read(unsigned long long* out) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || !g_last_ws[dev]) return ALILQR_E_HIP;
   if (hipDeviceSynchronize() != hipSuccess) return ALILQR_E_HIP;
-  if (hipMemcpy(out, (char*)g_last_ws[dev] + 128, 9 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return ALILQR_E_HIP;
+  if (hipMemcpy(out, (char*)g_last_ws[dev] + 128, 11 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return ALILQR_E_HIP;
   return ALILQR_OK;
 }
 #endif

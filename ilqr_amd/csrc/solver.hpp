@@ -39,6 +39,7 @@
 // cilqr/fast_ilqr.py:10-176 (FAST).
 #pragma once
 #include <cstddef>
+#include <type_traits>
 #include "models.hpp"
 
 namespace alilqr {
@@ -53,12 +54,17 @@ namespace alilqr {
 #endif
 
 #ifdef ALILQR_PROF
-#define PROF_DECL unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF_DECL unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_s0 = 0, prof_roll[2] = {0, 0};
 #define PROF_MARK(i) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += t_ - prof_t0; prof_t0 = t_; }
-#define PROF_FLUSH(a) { unsigned long long* const pr_ = ALILQR_COLD(prof); if (lane == 0 && pr_) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(pr_ + i_, prof_acc[i_]); atomicAdd(pr_ + 8, 1ull); } }
+// a roll-out pass: PASS_START / PASS_END around it (cycles inside roll-outs, number of passes)
+#define PASS_START { prof_roll[1] += 1; prof_s0 = __builtin_amdgcn_s_memtime(); }
+#define PASS_END { prof_roll[0] += __builtin_amdgcn_s_memtime() - prof_s0; }
+#define PROF_FLUSH(a) { unsigned long long* const pr_ = ALILQR_COLD(prof); if (lane == 0 && pr_) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(pr_ + i_, prof_acc[i_]); atomicAdd(pr_ + 8, 1ull); atomicAdd(pr_ + 9, prof_roll[0]); atomicAdd(pr_ + 10, prof_roll[1]); } }
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
+#define PASS_START
+#define PASS_END
 #define PROF_FLUSH(a)
 #endif
 
@@ -203,6 +209,7 @@ struct KArgs {
   unsigned long long quad_rows;   // rows whose quadratic matrix is not all zero, over all tables (kernel prologue)
   int sparse_rows;            // host: the one shared linear table may be searched for all-zero A / B rows
   unsigned long long azero, bzero;   // NEW_AL: rows whose A (B) entries are all zero (kernel prologue; 0 = none known)
+  int rows_lds;               // NEW_AL: doubles of a node's multiplier block the roll-outs copy to LDS one step ahead (launch)
   int live_rows;              // host: roll-outs may skip rows that cannot contribute (all-zero table row, zero multiplier)
   unsigned long long zrows;   // NEW_AL: rows of the shared table that are all zero (kernel prologue; 0 = none known)
   ModelConst mc;
@@ -806,6 +813,64 @@ __host__ __device__ constexpr bool is_rect(int mode) { return mode == kModeNewAl
 // With RECT a node's record carries, behind its C multipliers, an overlay of its constraint table: C row signs
 // (0: row as in the shared table; +-1: row replaced by  sign * y + B_i u + C'_i <= 0), C replacement constants C'_i
 // and the node's row index (LinearConstraints::UpdateConstraints, linear_constraints.h:360-373).
+// The multipliers (and rectangle overlay) of a node as the row loops of the C++ generation read them: from the node's
+// record in memory (a pointer and an element stride), or - the roll-outs - from LDS, where the lanes of the group have
+// copied the block one step ahead (RowsLds).  The copy is a direct global -> LDS load, 16 bytes per lane: lane gl of a
+// G-lane group brings doubles 2 gl, 2 gl + 1 of each chunk of 2 G doubles, and a chunk of the whole wave is 128 doubles
+// of LDS (the hardware writes lane l at byte 16 l).
+template <int CHD>
+struct RowsLds {
+  ltab p;              // the buffer + this lane's group offset (doubles)
+  __device__ __forceinline__ double at(int k) const { return p[(k / CHD) * 128 + (k % CHD)]; }
+};
+template <class LS>
+__device__ __forceinline__ double lam_at(const LS& lam, size_t ls, int k) {
+  if constexpr (std::is_class<LS>::value) return lam.at(k);
+  else return lam[(size_t)k * ls];
+}
+// Issue the copy of `nch` chunks of the block at `src` into the LDS buffer `dst` (uniform); gl = lane inside the group.
+// The copies are issued from inline assembly: the compiler's wait-count pass makes every LDS read after a direct-to-LDS
+// load it knows of wait for ALL outstanding memory operations, which is the wait this copy exists to avoid.  What
+// orders the reads instead is the returned token: an ordinary 4-byte load issued behind the copies.  Memory operations
+// return in order, so when the token has arrived the copies have landed; rows_bind() makes the LDS address of the
+// reads depend on the token, and the compiler counts the operations issued since itself.  (Operations the compiler does
+// not know of only make its other waits stricter: it waits for a load until at most as many operations are outstanding
+// as IT issued since, and ours are among the outstanding ones.)  M0 (the LDS base of the copy) is saved and restored.
+template <int G>
+__device__ __forceinline__ int rows_dma(const double* src, double* dst, int nch, int gl) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  unsigned int ldsb = (unsigned int)(unsigned long long)(__attribute__((address_space(3))) void*)dst;
+#pragma clang diagnostic pop
+  ldsb = __builtin_amdgcn_readfirstlane(ldsb);      // uniform by construction; the constraint below needs a scalar register
+  const double* s = src + 2 * gl;
+  for (int ch = 0; ch < nch; ++ch) {
+    unsigned int keep_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0) : "v"(s), "s"(ldsb) : "memory");
+    s += 2 * G;
+    ldsb += 1024;
+  }
+  return *(const int*)src;
+#else
+  const int lane = threadIdx.x & 63;
+  for (int ch = 0; ch < nch; ++ch)
+    for (int e = 0; e < 2; ++e) dst[(size_t)ch * 128 + 2 * lane + e] = src[(size_t)ch * (2 * G) + 2 * gl + e];
+  __threadfence_block();
+  return 0;
+#endif
+}
+// an LDS offset that is not formed before the token of the copy has arrived
+__device__ __forceinline__ int rows_bind(int off, int token) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(off) : "v"(token));
+#else
+  (void)token;
+#endif
+  return off;
+}
+
 template <int MODEL, bool QUAD, bool RECT>
 struct NewAlOps {
   using MD = Model<MODEL>;
@@ -858,16 +923,16 @@ struct NewAlOps {
     const unsigned int nb = *(const unsigned int __attribute__((address_space(4)))*)a.box_rows;
     return nb == (unsigned)NBOX && !__any(!all_finite<N, M>(x, u));
   }
-  template <class F>
-  __device__ static __forceinline__ void for_rows(const KArgs& a, const double* lam, size_t ls, F&& f, int first = 0) {
+  template <class LS, class F>
+  __device__ static __forceinline__ void for_rows(const KArgs& a, const LS& lam, size_t ls, F&& f, int first = 0) {
     for (int i0 = first; i0 < a.C; i0 += ROWS_AHEAD) {
       Row r[ROWS_AHEAD];
 #pragma unroll
       for (int q = 0; q < ROWS_AHEAD; ++q) {
         const bool in = i0 + q < a.C;
-        r[q].l = in ? lam[(size_t)(i0 + q) * ls] : 0.0;
-        r[q].sgn = (RECT && in) ? lam[(size_t)(a.C + i0 + q) * ls] : 0.0;
-        r[q].cn = (RECT && in) ? lam[(size_t)(2 * a.C + i0 + q) * ls] : 0.0;
+        r[q].l = in ? lam_at(lam, ls, i0 + q) : 0.0;
+        r[q].sgn = (RECT && in) ? lam_at(lam, ls, a.C + i0 + q) : 0.0;
+        r[q].cn = (RECT && in) ? lam_at(lam, ls, 2 * a.C + i0 + q) : 0.0;
       }
 #pragma unroll
       for (int q = 0; q < ROWS_AHEAD; ++q)
@@ -877,15 +942,15 @@ struct NewAlOps {
   // The rows of the bit mask `m` (uniform over the wave) in order.  The roll-outs skip rows that cannot contribute: a row
   // whose table entries are all zero, whose rectangle overlay is empty and whose multiplier is zero adds
   // (min(0 - mu * 0, 0))^2 = +0 to one sum and 0^2 = +0 to the other at a finite point - no bit of the cost changes.
-  template <class F>
-  __device__ static __forceinline__ void for_live(const KArgs& a, const double* lam, size_t ls, unsigned long long m, F&& f) {
+  template <class LS, class F>
+  __device__ static __forceinline__ void for_live(const KArgs& a, const LS& lam, size_t ls, unsigned long long m, F&& f) {
     while (m != 0ull) {
       const int i = __builtin_ctzll(m);
       m &= m - 1ull;
       Row r;
-      r.l = lam[(size_t)i * ls];
-      r.sgn = RECT ? lam[(size_t)(a.C + i) * ls] : 0.0;
-      r.cn = RECT ? lam[(size_t)(2 * a.C + i) * ls] : 0.0;
+      r.l = lam_at(lam, ls, i);
+      r.sgn = RECT ? lam_at(lam, ls, a.C + i) : 0.0;
+      r.cn = RECT ? lam_at(lam, ls, 2 * a.C + i) : 0.0;
       f(i, r);
     }
   }
@@ -998,10 +1063,10 @@ struct NewAlOps {
     if (QUAD) c = c + quad_term(a, tab, x, i);
     return c;
   }
-  template <bool LIVE = false, class TP>
+  template <bool LIVE = false, class TP, class LS>
   __device__ static double cost(const KArgs& a, TP Q, TP R, TP tab,
                                 const double* x, const double* u, const double* g,
-                                const double* lam, size_t ls, double mu, unsigned long long live = ~0ull) {
+                                const LS& lam, size_t ls, double mu, unsigned long long live = ~0ull) {
     double sc = 0.0, cc = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) { double e = x[i] - g[i]; sc += (e * Q[i * N + i]) * e; }
@@ -1014,7 +1079,7 @@ struct NewAlOps {
 #pragma unroll
       for (int i = 0; i < NBOX; ++i) {
         const BoxRow<N, M> row{i};
-        const double l = lam[(size_t)i * ls];
+        const double l = lam_at(lam, ls, i);
         const double f = l - mu * ((row.dot(x, u) + 0.0) + Cv[i]);
         double lp = a.eq ? f : fmin(f, 0.0);
         pp += lp * lp;
@@ -1034,10 +1099,10 @@ struct NewAlOps {
     return sc + cc + 0.5 / mu * (pp - ll);
   }
   // one column of parallel_cost / parallel_augmented_lagrangian_cost (constraints.h:558-580)
-  template <bool LIVE = false, class TP>
+  template <bool LIVE = false, class TP, class LS>
   __device__ static double par_cost(const KArgs& a, TP Q, TP R, TP tab,
                                     const double* x, const double* u, const double* g,
-                                    const double* lam, size_t ls, double mu, unsigned long long live = ~0ull) {
+                                    const LS& lam, size_t ls, double mu, unsigned long long live = ~0ull) {
     double cq = 0.0, cr = 0.0, al = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) { double e = x[i] - g[i]; cq += e * (e * Q[i * N + i]); }
@@ -1049,7 +1114,7 @@ struct NewAlOps {
 #pragma unroll
       for (int i = 0; i < NBOX; ++i) {
         const BoxRow<N, M> row{i};
-        const double l = lam[(size_t)i * ls];
+        const double l = lam_at(lam, ls, i);
         const double f = l - mu * ((row.dot(x, u) + 0.0) + Cv[i]);
         double pr = a.eq ? f : fmin(f, 0.0);
         al += pr * pr - l * l;
@@ -1298,9 +1363,14 @@ __host__ __device__ inline size_t block_doubles(int H, int C) {
 #ifndef ALILQR_MINW_N6
 #define ALILQR_MINW_N6 1   // waves per SIMD the 6-state kernels are compiled for (512 registers per lane)
 #endif
-// trajectory slots per problem and parity: the usual winners + one spare for a repeated roll-out
-template <int MODE>
-struct TrjSlots { static constexpr int SS = (MODE == ALILQR_MODE_LEGACY) ? 4 : 8; };
+// trajectory slots per problem and parity: the usual winners + one spare for a repeated roll-out.  The 6-state kernels
+// of the C++ generation keep all ten trials (a winner among trials 8-10 - one iteration in ten - costs them a whole
+// further pass otherwise: +3 to +9 % measured); the 4-state ones keep seven: at large batches the trajectory writes of
+// the three extra lanes cost more than the repeats (65536 lateral problems: 253 k against 235 k solves/s).
+template <int MODE, int N>
+struct TrjSlots {
+  static constexpr int SS = (MODE == ALILQR_MODE_LEGACY) ? 4 : (MODE == ALILQR_MODE_FAST || N <= 4) ? 8 : 11;
+};
 
 // f_xx of a node, only the C++ generation has it
 template <class MD, bool ON>
@@ -1322,7 +1392,9 @@ struct FxxOf<MD, true> {
 // LDS bytes hold the accumulated controls of the open-loop line-search trials afterwards: the records are dead once
 // the Riccati sweep has read them, the controls are written after it and dead when the line search ends; 3 (LEGACY,
 // 32 lanes) in LDS in their packed form.
-template <int MODEL, int MODE, int G, int LDSLIN = 0, int MINW = 0>
+// ROWS (C++ generation): 1 the roll-outs read a node's multiplier block from LDS buffers filled one step ahead (the
+// host launches this form where the buffers fit), 0 from the node's record.
+template <int MODEL, int MODE, int G, int LDSLIN = 0, int MINW = 0, int ROWS = 0>
 __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : ALILQR_MINW_N6))) void solve_kernel(KArgs a) {
   using MD = Model<MODEL>;
   using OPS = NodeOps<MODEL, MODE>;
@@ -1348,7 +1420,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   constexpr bool LWIDE = LEGACY && !(G < 32 && ALILQR_LEGACY_ROUNDS);
   constexpr bool PM = true;                            // block layout: problem-major (one contiguous block per group)
   constexpr int CL = LEGACY ? (MD::CTRL_ROWS ? 2 * (N + M) : 2 * N) : 1;         // multipliers held in registers (LEGACY only)
-  constexpr int SS = TrjSlots<MODE>::SS;               // trajectory slots kept per problem and parity
+  constexpr int SS = TrjSlots<MODE, N>::SS;               // trajectory slots kept per problem and parity
 
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);                       // lane inside the group
@@ -1514,6 +1586,17 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
     }
   };
   if (TLDS && a.table_nodes <= 1) stage_tables(0);
+  // NEW_AL roll-outs read a node's multipliers (and rectangle overlay) from LDS: the lanes of the group copy the block of
+  // node t + 1 while step t computes (RowsLds / rows_dma above), two buffers by node parity, behind the staged tables.
+  // With the block behind ordinary loads, every step waited for them - and, memory operations returning in order, for
+  // the trajectory stores of the step before; the copy is one step old when it is needed and its wait leaves the newer
+  // stores in flight.
+  constexpr int CHD = 2 * G;                                        // doubles of a group's chunk (16 bytes per lane)
+  constexpr bool RLDS = NEWAL && (ROWS != 0);
+  const int rows_lim = RLDS ? a.rows_lds : 0;                      // doubles of the block
+  const int rows_nch = (rows_lim + CHD - 1) / CHD;                 // chunks per node
+  const int rows_off = TLDS ? ((cw + N * N + M * M + 1) & ~1) : 0;  // first double of the buffers (16-byte aligned)
+  (void)ALILQR_CHK(!RLDS || (size_t)(rows_off + 2 * rows_nch * 128) * sizeof(double) <= (size_t)a.lds_bytes, 17);
 
   // goal list of problem q (clamped: idle groups still form addresses)
   auto goal_of = [&](int q) -> const double* {
@@ -2064,8 +2147,11 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           return tg.blk + (size_t)t * RS * ES;
         };
         const bool closed = !(LEGACY && kind == 1);
+        PASS_START
         RecRegs RA, RB;
         load_rec(tg, 0, RA, closed);
+        int rows_tok = 0;                              // NEW_AL: token of the multiplier copy in flight (rows_dma)
+        if constexpr (RLDS) rows_tok = rows_dma<G>(rec(0) + (size_t)RL::rl * ES, lds_pool + rows_off, rows_nch, gl);
 #pragma unroll
         for (int i = 0; i < N; ++i) x[i] = tg.cur[i];
         double uown[M];
@@ -2103,38 +2189,50 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
               else u[r] = (R.u[r] + alpha * R.k[r]) + fb;
             }
           }
-          if (valid) {
-            double xn[N];
-            // The node's (x_t, u_t) is stored between its cost and its dynamics: the stores then complete under the
-            // dynamics' arithmetic instead of ahead of the next node's loads (loads and stores share one in-order
-            // counter, so a wait for a load also waits for every store issued before it).
-            auto keep = [&]() {
-              if (sslot >= 0) {
+          // The node's (x_t, u_t) is stored between its cost and its dynamics: the stores then complete under the
+          // dynamics' arithmetic instead of ahead of the next node's loads (loads and stores share one in-order
+          // counter, so a wait for a load also waits for every store issued before it).
+          auto keep = [&]() {
+            if (sslot >= 0) {
 #pragma unroll
-                for (int r = 0; r < M; ++r) tout[XS + t * M + r] = u[r];
+              for (int r = 0; r < M; ++r) tout[XS + t * M + r] = u[r];
 #pragma unroll
-                for (int i = 0; i < N; ++i) tout[t * N + i] = x[i];
-              }
-            };
-            if constexpr (NEWAL) {
-              const double* lp = rec(t) + (size_t)RL::rl * ES;
-              if (kind == 2) {
-                J += OPS::template par_cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
-                keep();
-                MD::par_step(mc, x, u, xn);
+              for (int i = 0; i < N; ++i) tout[t * N + i] = x[i];
+            }
+          };
+          if constexpr (NEWAL) {
+            if (valid) {
+              if constexpr (RLDS) {
+                const RowsLds<CHD> lp{as_ltab(lds_pool + rows_off + (size_t)(t & 1) * rows_nch * 128) + rows_bind((lane / G) * CHD, rows_tok)};
+                if (kind == 2) J += OPS::template par_cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
+                else J += OPS::template cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
               } else {
-                J += OPS::template cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
-                keep();
-                MD::template step<false>(mc, x, u, xn);
+                const double* lp = rec(t) + (size_t)RL::rl * ES;
+                if (kind == 2) J += OPS::template par_cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
+                else J += OPS::template cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
               }
-            } else {
+            }
+            // the next node's multiplier block: every lane of the group brings its 16 bytes, issued behind this node's
+            // LDS reads and ahead of its stores (the wait for the copy then leaves the stores in flight)
+            if constexpr (RLDS) rows_tok = rows_dma<G>(rec(t + 1) + (size_t)RL::rl * ES, lds_pool + rows_off + (size_t)((t + 1) & 1) * rows_nch * 128, rows_nch, gl);
+            if (valid) {
+              double xn[N];
+              keep();
+              if (kind == 2) MD::par_step(mc, x, u, xn);
+              else MD::template step<false>(mc, x, u, xn);
+#pragma unroll
+              for (int i = 0; i < N; ++i) x[i] = xn[i];
+            }
+          } else {
+            if (valid) {
+              double xn[N];
               if (LEGACY) J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, R.lam, 1, mu);
               else J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, rec(t) + (size_t)RL::rl * ES, ES, mu);
               keep();
               MD::template step<true>(mc, x, u, xn);
-            }
 #pragma unroll
-            for (int i = 0; i < N; ++i) x[i] = xn[i];
+              for (int i = 0; i < N; ++i) x[i] = xn[i];
+            }
           }
 #pragma unroll
           for (int r = 0; r < M; ++r) uown[r] = unext[r];
@@ -2162,15 +2260,22 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
 #pragma unroll
           for (int r = 0; r < M; ++r) zu[r] = 0.0;
           if constexpr (NEWAL) {
-            const double* lp = rec(H) + (size_t)RL::rl * ES;
             if (TLDS && a.table_nodes > 1) stage_tables(H);
-            if (kind == 2) J += OPS::template par_cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
-            else J += OPS::template cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
+            if constexpr (RLDS) {
+              const RowsLds<CHD> lp{as_ltab(lds_pool + rows_off + (size_t)(H & 1) * rows_nch * 128) + rows_bind((lane / G) * CHD, rows_tok)};
+              if (kind == 2) J += OPS::template par_cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
+              else J += OPS::template cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
+            } else {
+              const double* lp = rec(H) + (size_t)RL::rl * ES;
+              if (kind == 2) J += OPS::template par_cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
+              else J += OPS::template cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
+            }
           } else {
             if (LEGACY) J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, RA.lam, 1, mu);
             else J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, rec(H) + (size_t)RL::rl * ES, ES, mu);
           }
         }
+        PASS_END
         return J;
       };
       auto alpha_of = [&](int j) -> double {     // 2^-(j-1) by exact halvings (ilqr.py:136)

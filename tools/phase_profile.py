@@ -44,7 +44,7 @@ def main():
     s.run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); o = s.run(); e1.record(); torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 9)()
+    buf = (C.c_ulonglong * 11)()
     assert lib.alilqr_prof_read(buf) == 0
     v = np.array(list(buf), dtype=np.float64)
     names = ["pull+init", "outer-start cost", "P1 linearise", "P2 riccati", "P3 rollouts", "P4 bookkeeping", "-", "group 0 idle, others busy"]
@@ -54,6 +54,8 @@ def main():
     print(f"{wl} lanes={os.environ.get('ALILQR_LANES','auto')} B={B} kernel {e0.elapsed_time(e1):.1f} ms  waves {int(waves)}  mean wave busy {tot/waves/1e6:.1f} Mcycles  mean inner {st[:,0].mean():.1f}")
     for n, x in zip(names, v[:8]):
         print(f"  {n:26s} {100*x/tot:6.2f} %   {x/waves/1e6:8.2f} Mcyc/wave")
+    if v[10] > 0:
+        print(f"  roll-out passes {int(v[10])}: {v[9]/v[10]:.0f} cycles per pass inside the roll-out, {(v[4]-v[9])/v[10]:.0f} in the rest of P3")
 
 if __name__ == "__main__":
     main()
