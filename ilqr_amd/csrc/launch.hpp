@@ -84,17 +84,17 @@ inline int launch_family(const KArgs& ka, int G, int waves, hipStream_t st, int 
     const size_t cw = (size_t)ka.C * (MDx::N + MDx::M + 1) + (size_t)ka.C * MDx::N * MDx::N;
     tl = (((cw + MDx::N * MDx::N + MDx::M * MDx::M + 1) & ~(size_t)1)) * sizeof(double);
   }
-  // NEW_AL: two LDS buffers for the multiplier block (C doubles; 3 C + 1 with the rectangle overlay) of the node a
+  // FAST / NEW_AL: two LDS buffers for the multiplier block (C doubles; 3 C + 1 with the rectangle overlay) of the node a
   // roll-out evaluates next, in chunks of 2 G doubles per group = 1 KB per wave.  Blocks of more than 8 chunks (16 KB of
   // buffers; a wave's share of the LDS at two waves per SIMD is 20 KB) are read from the records instead.
-  if constexpr (is_new_al(MODE)) {
+  if constexpr (MODE != ALILQR_MODE_LEGACY) {
     const int block = is_rect(MODE) ? 3 * ka.C + 1 : ka.C;
     const int chd = 2 * G;
     const int nch = (block + chd - 1) / chd;
     // Measured (solves/s against the form that reads the records, 4096 / 32768-65536 problems): 6-state tables +6 to +14 %
     // at 8 and 16 lanes, +5 % at 32; 4-state linear tables +3 to +9 % at 16 lanes, but -45 % at 8 lanes and -13 to -40 %
     // at 32 lanes with rectangle or quadratic rows (their register allocation suffers).  The form is therefore built
-    // and used for the 6-state kernels at 8 lanes and up and for the 4-state linear-table kernels at 16 lanes.
+    // and used for the 6-state kernels (FAST included) at 8 lanes and up and for the 4-state linear-table kernels at 16 lanes.
     constexpr bool six = Model<MODEL>::N > 4;
     const bool wanted = six ? (G >= 8) : (G == 16 && !is_quad(MODE));
     const bool fits = wanted && nch <= 8 && tl + (size_t)2 * nch * 1024 <= 40 * 1024;
@@ -102,7 +102,7 @@ inline int launch_family(const KArgs& ka, int G, int waves, hipStream_t st, int 
     if (fits) tl += (size_t)2 * nch * 1024;
   }
   kt.lds_bytes = (int)tl;
-  if constexpr (is_new_al(MODE)) {
+  if constexpr (MODE != ALILQR_MODE_LEGACY) {
     if (kt.rows_lds > 0) {
 #ifdef ALILQR_ONLY_G
       if (G != ALILQR_ONLY_G) return LAUNCH_BAD_WIDTH;

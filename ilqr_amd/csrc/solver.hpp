@@ -634,6 +634,64 @@ struct NodeOps<MODEL, ALILQR_MODE_LEGACY> {
   }
 };
 
+// The multipliers (and rectangle overlay) of a node as the row loops of the FAST and C++ generations read them: from the node's
+// record in memory (a pointer and an element stride), or - the roll-outs - from LDS, where the lanes of the group have
+// copied the block one step ahead (RowsLds).  The copy is a direct global -> LDS load, 16 bytes per lane: lane gl of a
+// G-lane group brings doubles 2 gl, 2 gl + 1 of each chunk of 2 G doubles, and a chunk of the whole wave is 128 doubles
+// of LDS (the hardware writes lane l at byte 16 l).
+template <int CHD>
+struct RowsLds {
+  ltab p;              // the buffer + this lane's group offset (doubles)
+  __device__ __forceinline__ double at(int k) const { return p[(k / CHD) * 128 + (k % CHD)]; }
+};
+template <class LS>
+__device__ __forceinline__ double lam_at(const LS& lam, size_t ls, int k) {
+  if constexpr (std::is_class<LS>::value) return lam.at(k);
+  else return lam[(size_t)k * ls];
+}
+// Issue the copy of `nch` chunks of the block at `src` into the LDS buffer `dst` (uniform); gl = lane inside the group.
+// The copies are issued from inline assembly: the compiler's wait-count pass makes every LDS read after a direct-to-LDS
+// load it knows of wait for ALL outstanding memory operations, which is the wait this copy exists to avoid.  What
+// orders the reads instead is the returned token: an ordinary 4-byte load issued behind the copies.  Memory operations
+// return in order, so when the token has arrived the copies have landed; rows_bind() makes the LDS address of the
+// reads depend on the token, and the compiler counts the operations issued since itself.  (Operations the compiler does
+// not know of only make its other waits stricter: it waits for a load until at most as many operations are outstanding
+// as IT issued since, and ours are among the outstanding ones.)  M0 (the LDS base of the copy) is saved and restored.
+template <int G>
+__device__ __forceinline__ int rows_dma(const double* src, double* dst, int nch, int gl) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  unsigned int ldsb = (unsigned int)(unsigned long long)(__attribute__((address_space(3))) void*)dst;
+#pragma clang diagnostic pop
+  ldsb = __builtin_amdgcn_readfirstlane(ldsb);      // uniform by construction; the constraint below needs a scalar register
+  const double* s = src + 2 * gl;
+  for (int ch = 0; ch < nch; ++ch) {
+    unsigned int keep_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0) : "v"(s), "s"(ldsb) : "memory");
+    s += 2 * G;
+    ldsb += 1024;
+  }
+  return *(const int*)src;
+#else
+  const int lane = threadIdx.x & 63;
+  for (int ch = 0; ch < nch; ++ch)
+    for (int e = 0; e < 2; ++e) dst[(size_t)ch * 128 + 2 * lane + e] = src[(size_t)ch * (2 * G) + 2 * gl + e];
+  __threadfence_block();
+  return 0;
+#endif
+}
+// an LDS offset that is not formed before the token of the copy has arrived
+__device__ __forceinline__ int rows_bind(int off, int token) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(off) : "v"(token));
+#else
+  (void)token;
+#endif
+  return off;
+}
+
 // FAST: projection-form AL over a linear table c(x,u) = A x + B u + C <= 0
 // (cilqr/constraints.py:47-119, linear_constraints.py:13-29, fast_bicycle_node.py:183-212)
 template <int MODEL>
@@ -660,20 +718,21 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
   }
   // Rows first .. C-1 in order, their multipliers loaded ROWS_AHEAD at a time before the first of them is used.
   static constexpr int ROWS_AHEAD = 1;   // measured: more rows ahead change nothing (the row loop is bound by its arithmetic)
-  template <class F>
-  __device__ static __forceinline__ void for_rows(const KArgs& a, const double* lam, size_t ls, F&& f, int first = 0) {
+  template <class LS, class F>
+  __device__ static __forceinline__ void for_rows(const KArgs& a, const LS& lam, size_t ls, F&& f, int first = 0) {
     for (int i0 = first; i0 < a.C; i0 += ROWS_AHEAD) {
       double l[ROWS_AHEAD];
 #pragma unroll
-      for (int q = 0; q < ROWS_AHEAD; ++q) l[q] = (i0 + q < a.C) ? lam[(size_t)(i0 + q) * ls] : 0.0;
+      for (int q = 0; q < ROWS_AHEAD; ++q) l[q] = (i0 + q < a.C) ? lam_at(lam, ls, i0 + q) : 0.0;
 #pragma unroll
       for (int q = 0; q < ROWS_AHEAD; ++q)
         if (i0 + q < a.C) f(i0 + q, l[q]);
     }
   }
+  template <class LS>
   __device__ static double cost(const KArgs& a, ctab Q, ctab R, ctab tab,
                                 const double* x, const double* u, const double* g,
-                                const double* lam, size_t ls, double mu) {
+                                const LS& lam, size_t ls, double mu) {
     double e[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) e[i] = x[i] - g[i];
@@ -686,7 +745,7 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
 #pragma unroll
       for (int i = 0; i < NBOX; ++i) {
         const BoxRow<N, M> row{i};
-        const double l = lam[(size_t)i * ls];
+        const double l = lam_at(lam, ls, i);
         double f = l - mu * ((row.dot(x, u) + 0.0) + Cv[i]);
         double lp = a.eq ? f : fmin(f, 0.0);
         pp += lp * lp;
@@ -813,63 +872,6 @@ __host__ __device__ constexpr bool is_rect(int mode) { return mode == kModeNewAl
 // With RECT a node's record carries, behind its C multipliers, an overlay of its constraint table: C row signs
 // (0: row as in the shared table; +-1: row replaced by  sign * y + B_i u + C'_i <= 0), C replacement constants C'_i
 // and the node's row index (LinearConstraints::UpdateConstraints, linear_constraints.h:360-373).
-// The multipliers (and rectangle overlay) of a node as the row loops of the C++ generation read them: from the node's
-// record in memory (a pointer and an element stride), or - the roll-outs - from LDS, where the lanes of the group have
-// copied the block one step ahead (RowsLds).  The copy is a direct global -> LDS load, 16 bytes per lane: lane gl of a
-// G-lane group brings doubles 2 gl, 2 gl + 1 of each chunk of 2 G doubles, and a chunk of the whole wave is 128 doubles
-// of LDS (the hardware writes lane l at byte 16 l).
-template <int CHD>
-struct RowsLds {
-  ltab p;              // the buffer + this lane's group offset (doubles)
-  __device__ __forceinline__ double at(int k) const { return p[(k / CHD) * 128 + (k % CHD)]; }
-};
-template <class LS>
-__device__ __forceinline__ double lam_at(const LS& lam, size_t ls, int k) {
-  if constexpr (std::is_class<LS>::value) return lam.at(k);
-  else return lam[(size_t)k * ls];
-}
-// Issue the copy of `nch` chunks of the block at `src` into the LDS buffer `dst` (uniform); gl = lane inside the group.
-// The copies are issued from inline assembly: the compiler's wait-count pass makes every LDS read after a direct-to-LDS
-// load it knows of wait for ALL outstanding memory operations, which is the wait this copy exists to avoid.  What
-// orders the reads instead is the returned token: an ordinary 4-byte load issued behind the copies.  Memory operations
-// return in order, so when the token has arrived the copies have landed; rows_bind() makes the LDS address of the
-// reads depend on the token, and the compiler counts the operations issued since itself.  (Operations the compiler does
-// not know of only make its other waits stricter: it waits for a load until at most as many operations are outstanding
-// as IT issued since, and ours are among the outstanding ones.)  M0 (the LDS base of the copy) is saved and restored.
-template <int G>
-__device__ __forceinline__ int rows_dma(const double* src, double* dst, int nch, int gl) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-  unsigned int ldsb = (unsigned int)(unsigned long long)(__attribute__((address_space(3))) void*)dst;
-#pragma clang diagnostic pop
-  ldsb = __builtin_amdgcn_readfirstlane(ldsb);      // uniform by construction; the constraint below needs a scalar register
-  const double* s = src + 2 * gl;
-  for (int ch = 0; ch < nch; ++ch) {
-    unsigned int keep_m0;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep_m0) : "v"(s), "s"(ldsb) : "memory");
-    s += 2 * G;
-    ldsb += 1024;
-  }
-  return *(const int*)src;
-#else
-  const int lane = threadIdx.x & 63;
-  for (int ch = 0; ch < nch; ++ch)
-    for (int e = 0; e < 2; ++e) dst[(size_t)ch * 128 + 2 * lane + e] = src[(size_t)ch * (2 * G) + 2 * gl + e];
-  __threadfence_block();
-  return 0;
-#endif
-}
-// an LDS offset that is not formed before the token of the copy has arrived
-__device__ __forceinline__ int rows_bind(int off, int token) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+v"(off) : "v"(token));
-#else
-  (void)token;
-#endif
-  return off;
-}
 
 template <int MODEL, bool QUAD, bool RECT>
 struct NewAlOps {
@@ -1392,7 +1394,7 @@ struct FxxOf<MD, true> {
 // LDS bytes hold the accumulated controls of the open-loop line-search trials afterwards: the records are dead once
 // the Riccati sweep has read them, the controls are written after it and dead when the line search ends; 3 (LEGACY,
 // 32 lanes) in LDS in their packed form.
-// ROWS (C++ generation): 1 the roll-outs read a node's multiplier block from LDS buffers filled one step ahead (the
+// ROWS (FAST and C++ generations): 1 the roll-outs read a node's multiplier block from LDS buffers filled one step ahead (the
 // host launches this form where the buffers fit), 0 from the node's record.
 template <int MODEL, int MODE, int G, int LDSLIN = 0, int MINW = 0, int ROWS = 0>
 __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_MINW_N4 : ALILQR_MINW_N6))) void solve_kernel(KArgs a) {
@@ -1592,7 +1594,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   // the trajectory stores of the step before; the copy is one step old when it is needed and its wait leaves the newer
   // stores in flight.
   constexpr int CHD = 2 * G;                                        // doubles of a group's chunk (16 bytes per lane)
-  constexpr bool RLDS = NEWAL && (ROWS != 0);
+  constexpr bool RLDS = !LEGACY && (ROWS != 0);
   const int rows_lim = RLDS ? a.rows_lds : 0;                      // doubles of the block
   const int rows_nch = (rows_lim + CHD - 1) / CHD;                 // chunks per node
   const int rows_off = TLDS ? ((cw + N * N + M * M + 1) & ~1) : 0;  // first double of the buffers (16-byte aligned)
@@ -2200,16 +2202,22 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
               for (int i = 0; i < N; ++i) tout[t * N + i] = x[i];
             }
           };
-          if constexpr (NEWAL) {
+          if constexpr (!LEGACY) {
             if (valid) {
+              auto node_J = [&](const auto& lp) -> double {
+                if constexpr (NEWAL) {
+                  if (kind == 2) return OPS::template par_cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
+                  return OPS::template cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
+                } else {
+                  return OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, lp, ES, mu);
+                }
+              };
               if constexpr (RLDS) {
                 const RowsLds<CHD> lp{as_ltab(lds_pool + rows_off + (size_t)(t & 1) * rows_nch * 128) + rows_bind((lane / G) * CHD, rows_tok)};
-                if (kind == 2) J += OPS::template par_cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
-                else J += OPS::template cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
+                J += node_J(lp);
               } else {
                 const double* lp = rec(t) + (size_t)RL::rl * ES;
-                if (kind == 2) J += OPS::template par_cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
-                else J += OPS::template cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
+                J += node_J(lp);
               }
             }
             // the next node's multiplier block: every lane of the group brings its 16 bytes, issued behind this node's
@@ -2218,16 +2226,19 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
             if (valid) {
               double xn[N];
               keep();
-              if (kind == 2) MD::par_step(mc, x, u, xn);
-              else MD::template step<false>(mc, x, u, xn);
+              if constexpr (NEWAL) {
+                if (kind == 2) MD::par_step(mc, x, u, xn);
+                else MD::template step<false>(mc, x, u, xn);
+              } else {
+                MD::template step<true>(mc, x, u, xn);
+              }
 #pragma unroll
               for (int i = 0; i < N; ++i) x[i] = xn[i];
             }
           } else {
             if (valid) {
               double xn[N];
-              if (LEGACY) J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, R.lam, 1, mu);
-              else J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, rec(t) + (size_t)RL::rl * ES, ES, mu);
+              J += OPS::cost(a, tabQ(t), tabR(t), tabC(t), x, u, R.g, R.lam, 1, mu);
               keep();
               MD::template step<true>(mc, x, u, xn);
 #pragma unroll
@@ -2259,20 +2270,25 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           double zu[M];
 #pragma unroll
           for (int r = 0; r < M; ++r) zu[r] = 0.0;
-          if constexpr (NEWAL) {
+          if constexpr (!LEGACY) {
             if (TLDS && a.table_nodes > 1) stage_tables(H);
+            auto node_J = [&](const auto& lp) -> double {
+              if constexpr (NEWAL) {
+                if (kind == 2) return OPS::template par_cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
+                return OPS::template cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
+              } else {
+                return OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, lp, ES, mu);
+              }
+            };
             if constexpr (RLDS) {
               const RowsLds<CHD> lp{as_ltab(lds_pool + rows_off + (size_t)(H & 1) * rows_nch * 128) + rows_bind((lane / G) * CHD, rows_tok)};
-              if (kind == 2) J += OPS::template par_cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
-              else J += OPS::template cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
+              J += node_J(lp);
             } else {
               const double* lp = rec(H) + (size_t)RL::rl * ES;
-              if (kind == 2) J += OPS::template par_cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
-              else J += OPS::template cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
+              J += node_J(lp);
             }
           } else {
-            if (LEGACY) J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, RA.lam, 1, mu);
-            else J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, rec(H) + (size_t)RL::rl * ES, ES, mu);
+            J += OPS::cost(a, tabQ(H), tabR(H), tabC(H), x, zu, RA.g, RA.lam, 1, mu);
           }
         }
         PASS_END
