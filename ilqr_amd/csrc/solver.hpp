@@ -1514,6 +1514,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   double mu_s = 1.0;          // NEW_AL: the solver's own penalty; the nodes' `mu` follows it from the first increase on
   int outer = 0, inner = 0, n_inner = 0, n_trials = 0;
   bool outer_start = false;
+  unsigned long long live_g = 0ull;   // NEW_AL: all-zero table rows with a live multiplier or overlay on this lane's nodes (see live_rows)
   // Each group is a small state machine that advances by at most one linearise + Riccati pass and one roll-out
   // pass per trip of the wave loop: a group whose line search needs further passes (more rounds of trials, the
   // ladder, a repeat) takes them in the following trips while the other groups of the wave, already on their
@@ -1875,12 +1876,17 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
     // the group's nodes, and a row that is live in any group of the wave is evaluated by the whole wave (evaluating a
     // dead row changes nothing).  Dead rows stay dead until the next row activation: their c is +0, so the multiplier
     // update leaves a zero multiplier at zero.
+    // The look happens where the multipliers or the overlay can have changed - a group's first trip with a problem, after
+    // a multiplier update (outer_start) and after a row activation - and its result (live_g) is kept in between.
     unsigned long long live_rows = ~0ull;
     if constexpr (LIVE) {
       const unsigned long long zr = a.zrows;
       if (zr != 0ull) {
-        unsigned long long lm = 0ull;
-        if (p >= 0) {
+        // (4-state kernels; the 6-state ones look on every trip: the two more registers of the kept mask cost them
+        //  7 to 12 %)
+        constexpr bool KEEP = N <= 4;
+        if (p >= 0 && (!KEEP || (phase == PH_LIN && (outer_start || tables_changed)))) {
+          unsigned long long lm = 0ull;
           for (int t = gl; t <= H; t += G) {
             const double* lp = rec(t) + (size_t)RL::rl * ES;
             for (unsigned long long z = zr; z != 0ull; z &= z - 1ull) {
@@ -1890,7 +1896,11 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
               if (nz) lm |= 1ull << i;
             }
           }
+          live_g = lm;                                  // this lane's nodes; the union over the wave is formed below
+        } else if (!KEEP) {
+          live_g = 0ull;
         }
+        const unsigned long long lm = (p >= 0) ? live_g : 0ull;
         live_rows = ~zr;
         for (unsigned long long z = zr; z != 0ull; z &= z - 1ull) {
           const int i = __builtin_ctzll(z);
