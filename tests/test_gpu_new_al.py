@@ -73,15 +73,31 @@ def test_new_al_matches_oracle(name, lanes, tuning):
     assert np.all(o["viol"][conv] < desc.prm.viol_stop)
 
 
-def test_new_al_lane_width_does_not_change_bits(tuning):
-    desc, x0, goals, Q, R, cons = problems.new_al_box(32, H=30, seed=9)
+WIDTH_SETS = {
+    "box6": lambda: problems.new_al_box(32, H=30, seed=9),
+    "lat4_ten_row_table": lambda: problems.new_al_lat(32, H=30, seed=9),       # two live rows, eight rows of zeros
+    "kin_rect": lambda: problems.kin_rect(32),                                 # rows the rectangle activation fills
+    "lat_rect": lambda: problems.new_al_lat_rect(32),
+    "circle6": lambda: problems.new_al_circle(32, H=30),
+    "fast_box_linear": lambda: problems.fast_box_linear(32, H=30),
+}
+
+
+@pytest.mark.parametrize("name", list(WIDTH_SETS))
+def test_new_al_lane_width_does_not_change_bits(name, tuning):
+    """1, 4, 8, 16 and 32 lanes per problem run different kernel forms (the 6-state kernels read the multipliers of a
+    roll-out step from LDS at 8 lanes and up, the 4-state linear-table kernels at 16; the narrower ones from the
+    records): same bits."""
+    prob, kw = WIDTH_SETS[name](), {}
+    if isinstance(prob[0], tuple):
+        prob, kw = prob
     outs = []
     for g in ("1", "4", "8", "16", "32"):
         tuning(lanes=int(g))
-        outs.append(to_np(batch.solve_batch(desc, x0, goals, Q, R, cons)))
+        outs.append(to_np(batch.solve_batch(*prob, **kw)))
     for o in outs[1:]:
         for k in ("x", "u", "cost", "status", "lam", "mu"):
-            assert np.array_equal(o[k], outs[0][k]), k
+            assert np.array_equal(o[k], outs[0][k], equal_nan=True), k
 
 
 def test_new_al_returned_pair_is_consistent():
