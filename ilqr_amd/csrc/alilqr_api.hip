@@ -910,7 +910,7 @@ int32_t alilqr_prof_read(unsigned long long* out) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || !g_last_ws[dev]) return ALILQR_E_HIP;
   if (hipDeviceSynchronize() != hipSuccess) return ALILQR_E_HIP;
-  if (hipMemcpy(out, (char*)g_last_ws[dev] + 128, 11 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return ALILQR_E_HIP;
+  if (hipMemcpy(out, (char*)g_last_ws[dev] + 128, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return ALILQR_E_HIP;
   return ALILQR_OK;
 }
 #endif

@@ -54,15 +54,31 @@ namespace alilqr {
 #endif
 
 #ifdef ALILQR_PROF
-#define PROF_DECL unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_s0 = 0, prof_roll[2] = {0, 0};
+#define PROF_DECL unsigned long long prof_t0 = __builtin_amdgcn_s_memtime(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_s0 = 0, prof_roll[2] = {0, 0}, prof_p0 = 0, prof_p3[5] = {0, 0, 0, 0, 0};
 #define PROF_MARK(i) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += t_ - prof_t0; prof_t0 = t_; }
 // a roll-out pass: PASS_START / PASS_END around it (cycles inside roll-outs, number of passes)
 #define PASS_START { prof_roll[1] += 1; prof_s0 = __builtin_amdgcn_s_memtime(); }
+#ifdef ALILQR_PROF_DRAIN   /* wait for every outstanding memory operation inside the measured region */
+#define PASS_END { __builtin_amdgcn_s_waitcnt(0x0F70); prof_roll[0] += __builtin_amdgcn_s_memtime() - prof_s0; }
+#else
 #define PASS_END { prof_roll[0] += __builtin_amdgcn_s_memtime() - prof_s0; }
-#define PROF_FLUSH(a) { unsigned long long* const pr_ = ALILQR_COLD(prof); if (lane == 0 && pr_) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(pr_ + i_, prof_acc[i_]); atomicAdd(pr_ + 8, 1ull); atomicAdd(pr_ + 9, prof_roll[0]); atomicAdd(pr_ + 10, prof_roll[1]); } }
+#endif
+// -DALILQR_PROF_P3: the roll-out phase in parts.  The accumulators are updated inside the (divergent) line-search loop,
+// so each lane keeps its own; lane 0's are reported: "last pass -> P3 end" is the time the wave spends on passes of
+// other groups after group 0's search has ended.
+#ifdef ALILQR_PROF_P3
+#define P3_STAMP(i) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_p3[i] += t_ - prof_p0; prof_p0 = t_; }
+#define P3_START { __builtin_amdgcn_s_waitcnt(0); prof_p0 = __builtin_amdgcn_s_memtime(); }
+#else
+#define P3_STAMP(i)
+#define P3_START
+#endif
+#define PROF_FLUSH(a) { unsigned long long* const pr_ = ALILQR_COLD(prof); if (lane == 0 && pr_) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(pr_ + i_, prof_acc[i_]); atomicAdd(pr_ + 8, 1ull); atomicAdd(pr_ + 9, prof_roll[0]); atomicAdd(pr_ + 10, prof_roll[1]); for (int i_ = 0; i_ < 5; ++i_) atomicAdd(pr_ + 11 + i_, prof_p3[i_]); } }
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
+#define P3_STAMP(i)
+#define P3_START
 #define PASS_START
 #define PASS_END
 #define PROF_FLUSH(a)
@@ -1412,10 +1428,13 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   constexpr bool NEWAL = is_new_al(MODE);
   constexpr bool QUAD = is_quad(MODE);
   constexpr bool RECT = is_rect(MODE);
-  // One roll-out pass per trip of the wave loop where a wave carries more than two groups (their line searches
-  // need different numbers of passes); with two groups per wave the passes of a line search run back to back,
-  // which also keeps the register allocation of the 6-state kernels tight.
-  constexpr bool TRIP = (G < 32) && (N <= 4 || ALILQR_TRIP_N6);
+  // One roll-out pass per trip of the wave loop where a wave carries more than two groups (their line searches need
+  // different numbers of passes, and with the passes of a search back to back the wave runs as many as its slowest
+  // group needs while the lanes of the others idle: half of the roll-out phase of 65536 kinematic + rectangle problems
+  // at 8 lanes).  The 4-state kernels and the 6-state FAST kernel (box + linear H = 100, 16384 problems: 74 k -> 83 k
+  // solves/s) take it; the 6-state NEW_AL kernels lose 20-30 % with it (register allocation) and keep the passes of
+  // a search back to back, as do two groups per wave.  (LEGACY searches are wave-wide, below.)
+  constexpr bool TRIP = (G < 32) && (N <= 4 || MODE == ALILQR_MODE_FAST || ALILQR_TRIP_N6);
   // LEGACY line search: wave-wide passes (below), or - a development switch, ALILQR_LEGACY_ROUNDS - for groups narrower
   // than 32 lanes the trials in rounds of G on the group's OWN lanes, one round per roll-out pass of the wave, through
   // the state machine of the other generations.
@@ -2093,6 +2112,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
 
     }
       PROF_MARK(3)
+      P3_START
       // ================= P3: roll-outs, one line-search trial per lane =================
       // What a roll-out reads and writes of a problem: the group's block (step records), the trajectory slots
       // of the parity being written, the penalty.  A lane normally works for its own group; in the compacted
@@ -2474,6 +2494,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
       // The passes of the line search (rounds of trials, the C++ generation's ladder, the repeat of a winner
       // whose trajectory was not kept) go through ONE roll-out call: the groups of a wave that are in
       // different passes still execute it together, and the roll-out code exists once.
+      P3_STAMP(0)                                   /* MARK(3) -> first loop top */
       while (stage != ST_DONE) {
         bool valid = true;
         int kind = 0, sslot = -1;
@@ -2499,7 +2520,9 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           if (LEGACY) uct = (win_trial >= 2) ? win_trial : 2;
         }
         __threadfence_block();
+        P3_STAMP(1)                                 /* loop top -> roll-out call */
         const double J = rollout(own, valid, kind, alpha, LEGACY ? ucgr + (uct - 2) : nullptr, UCSr, sslot);
+        P3_STAMP(2)                                 /* the roll-out */
 
         if (stage == ST_TRIALS) {
           const bool ok = valid && (J < old_cost);
@@ -2565,9 +2588,11 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           if (NEWAL && win_trial == 0) { new_cost = J; ++n_trials; }   // the ladder winner is re-run with the sequential arithmetic
           stage = ST_DONE;
         }
+        P3_STAMP(3)                                 /* bookkeeping after the roll-out */
         if (TRIP) break;                         // further passes in the following trips
       }
       }
+      P3_STAMP(4)                                   /* loop end -> MARK(4) */
       PROF_MARK(4)
      if (p >= 0 && stage == ST_DONE) {
       if (win_trial >= 0) cur_par = np_;

@@ -44,7 +44,7 @@ def main():
     s.run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); o = s.run(); e1.record(); torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 11)()
+    buf = (C.c_ulonglong * 16)()
     assert lib.alilqr_prof_read(buf) == 0
     v = np.array(list(buf), dtype=np.float64)
     names = ["pull+init", "outer-start cost", "P1 linearise", "P2 riccati", "P3 rollouts", "P4 bookkeeping", "-", "group 0 idle, others busy"]
@@ -56,6 +56,9 @@ def main():
         print(f"  {n:26s} {100*x/tot:6.2f} %   {x/waves/1e6:8.2f} Mcyc/wave")
     if v[10] > 0:
         print(f"  roll-out passes {int(v[10])}: {v[9]/v[10]:.0f} cycles per pass inside the roll-out, {(v[4]-v[9])/v[10]:.0f} in the rest of P3")
+    if v[11:16].sum() > 0:
+        names3 = ["P3 start -> first pass", "pass: before the roll-out", "pass: roll-out", "pass: after the roll-out", "last pass -> P3 end"]
+        print("  P3 in parts (Mcyc/wave): " + "; ".join(f"{n} {x/waves/1e6:.2f}" for n, x in zip(names3, v[11:16])))
 
 if __name__ == "__main__":
     main()
