@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds the kernel sources for the host (tools/host_emu/hip/hip_runtime.h stands in for the HIP runtime) with
-# AddressSanitizer and runs a few problems of every non-LEGACY kernel family at 1 and 4 emulated lanes per group.
+# AddressSanitizer and runs a few problems of every non-LEGACY kernel family at 1 and 4 emulated lanes per group
+# (LANES="1 4 8" adds the 8-lane kernels, which read the multipliers of a roll-out step from the emulated LDS).
 # The LEGACY line search reads the state of other groups of its wave; groups run one after the other here, so the
 # LEGACY families are not emulated.  Usage:  bash tools/host_emu/run_asan.sh [problems per set]
 # SAN=undefined runs the same under UndefinedBehaviorSanitizer (shifts, array bounds, signed overflow) instead.
