@@ -157,6 +157,18 @@ int pick_group(const alilqr_problem* p) {
   // second pass whenever one group of the wave finds no step, and the last solves of a batch - each alone in its wave -
   // take twice as long.  Measured at 40 960 and 81 920 lateral problems per launch: 32 lanes 228 k solves/s, 16 lanes 217 k.
   if (p->mode == ALILQR_MODE_LEGACY && p->n <= 4) return g0;
+  // FAST (6-state, one wave per SIMD = 1024 resident waves): the widest group that still gives every problem a resident
+  // group.  Its line search accepts the first trial four times out of five, and since the groups of a wave take their
+  // passes trip by trip, narrow groups lose little.  Measured (box + linear H = 100, one launch): 4096 problems 16 lanes
+  // 56 k solves/s (8: 50 k), 8192 8 lanes 79 k (16: 61 k, 4: 64 k), 16384 4 lanes 95 k (8: 82 k, 16: 71 k).
+  if (p->mode == ALILQR_MODE_FAST) {
+    const long one_per_simd = 1024;
+    return ((long)p->batch * 16 / 64 <= one_per_simd) ? 16 : ((long)p->batch * 8 / 64 <= one_per_simd) ? 8 : 4;
+  }
+  // The 6-state LEGACY models at large batches: 8 lanes.  Dynamic model H = 100: 16384 problems in one launch 34.3 k
+  // solves/s (16 lanes 32.0 k), six such batches in one call 61 k (16 lanes 50 k); kinematic model H = 50, 8192
+  // problems 40.7 k (16 lanes 27.4 k).
+  if (p->mode == ALILQR_MODE_LEGACY && p->batch >= 8192) return 8;
   return ((long)p->batch * g0 / 64 <= target_waves) ? g0 : g1;
 }
 
