@@ -165,9 +165,11 @@ int pick_group(const alilqr_problem* p) {
     const long one_per_simd = 1024;
     return ((long)p->batch * 16 / 64 <= one_per_simd) ? 16 : ((long)p->batch * 8 / 64 <= one_per_simd) ? 8 : 4;
   }
-  // The 6-state LEGACY models at large batches: 8 lanes.  Dynamic model H = 100: 16384 problems in one launch 34.3 k
-  // solves/s (16 lanes 32.0 k), six such batches in one call 61 k (16 lanes 50 k); kinematic model H = 50, 8192
-  // problems 40.7 k (16 lanes 27.4 k).
+  // The 6-state LEGACY models at large batches: 8 lanes from 8192 problems, 4 from 16384.  Dynamic model H = 100: 16384
+  // problems in one launch 34.5 k solves/s at 8 lanes, 33.0 k at 4 (16 lanes 32.0 k), six such batches in one call
+  // 66.7 k at 4 lanes, 60.8 k at 8, 50 k at 16; kinematic model H = 50: 8192 problems 40.6 k at 8 lanes (16 lanes
+  // 27.4 k, 4 lanes 29.6 k), 16384 problems 49.4 k at 4 lanes (8 lanes 40.9 k).
+  if (p->mode == ALILQR_MODE_LEGACY && p->batch >= 16384) return 4;
   if (p->mode == ALILQR_MODE_LEGACY && p->batch >= 8192) return 8;
   return ((long)p->batch * g0 / 64 <= target_waves) ? g0 : g1;
 }
