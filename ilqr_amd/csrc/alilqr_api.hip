@@ -171,6 +171,11 @@ int pick_group(const alilqr_problem* p) {
   // 27.4 k, 4 lanes 29.6 k), 16384 problems 49.4 k at 4 lanes (8 lanes 40.9 k).
   if (p->mode == ALILQR_MODE_LEGACY && p->batch >= 16384) return 4;
   if (p->mode == ALILQR_MODE_LEGACY && p->batch >= 8192) return 8;
+  // The 4-state NEW_AL model from 262144 problems: 4 lanes.  One launch of that size runs as fast at 4 lanes as at 16
+  // (lateral box set H = 50: 291 k against 295 k solves/s); with several launches in flight the narrow groups win
+  // (256 starts x 1024 scenarios, 12 calls in flight: 337 k at 4 lanes, 296 k at 8, 313 k at 16).  Smaller single
+  // launches lose at 4 lanes (131072 problems: 273 k against 288 k at 16).
+  if (p->mode == ALILQR_MODE_NEW_AL && p->n == 4 && p->batch >= 262144) return 4;
   return ((long)p->batch * g0 / 64 <= target_waves) ? g0 : g1;
 }
 
