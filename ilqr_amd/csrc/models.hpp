@@ -489,6 +489,35 @@ struct Model<ALILQR_MODEL_NEW_BICYCLE> : Full6Base {
 #pragma unroll
     for (int i = 0; i < 6; ++i) xn[i] = x[i] + k2[i] * mc.dt;
   }
+  // step() and par_step() as one instruction stream: `par` picks, lane by lane, the arithmetic of par_step.  Every value
+  // is formed by the operations of the function it stands for, in their order (a product's factors may be swapped), so
+  // the bits are those of step() or par_step(); lanes of both kinds share the sin / cos / tan evaluations.
+  __device__ static __forceinline__ void cont2(const ModelConst& mc, const double* s, const double* u, double* out, bool par) {
+    const double th = par ? s[2] : wrap_c(s[2]), de = par ? s[3] : wrap_c(s[3]);
+    const double v = s[4];
+    double sn, cs;
+    sincos_w(th, &sn, &cs);
+    out[0] = v * cs;
+    out[1] = v * sn;
+    const double vt = v * tan_w(de), den = 1 + mc.k * v * v;
+    if (par) out[2] = vt * (1.0 / den) / mc.L;
+    else out[2] = vt / (mc.L * den);
+    out[3] = u[0];
+    out[4] = s[5];
+    out[5] = u[1];
+  }
+  __device__ static void step2(const ModelConst& mc, const double* x, const double* u, double* xn, bool par) {
+    double k1[6], k2[6], mid[6];
+    cont2(mc, x, u, k1, par);
+    const double hdt = 0.5 * mc.dt;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) mid[i] = par ? x[i] + k1[i] * mc.dt * 0.5 : x[i] + hdt * k1[i];
+    cont2(mc, mid, u, k2, par);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xn[i] = x[i] + mc.dt * k2[i];
+    xn[2] = par ? xn[2] : wrap_c(xn[2]);
+    xn[3] = par ? xn[3] : wrap_c(xn[3]);
+  }
   // new_bicycle_node.h:492-545
   template <bool WRAPPED = false>
   __device__ static void jac(const ModelConst& mc, const double* x, const double* uc, double* a, double* b) {

@@ -101,8 +101,15 @@ __device__ __forceinline__ ltab as_ltab(const double* p) {
   return (ltab)p;
 #pragma clang diagnostic pop
 }
+// NEW_AL line search: the first columns of the ladder in the idle lanes of the last round of trials
+#ifndef ALILQR_LADDER_AHEAD
+#define ALILQR_LADDER_AHEAD 1
+#endif
 #ifndef ALILQR_TAB_LDS
 #define ALILQR_TAB_LDS 1
+#endif
+#ifndef ALILQR_MERGE_KINDS
+#define ALILQR_MERGE_KINDS 1
 #endif
 // a value that is the same in every lane, as a scalar (host builds: the value)
 __device__ __forceinline__ unsigned long long wave_uniform(unsigned long long m) {
@@ -1116,6 +1123,47 @@ struct NewAlOps {
     else for_rows(a, lam, ls, row, box ? NBOX : 0);
     return sc + cc + 0.5 / mu * (pp - ll);
   }
+  // cost() and par_cost() as one instruction stream for tables without quadratic rows: `par` picks, lane by lane, which
+  // of the two sums is returned.  The state and control terms of the two have the same bits (their products differ in
+  // the order of the factors only), the row values are the same; the penalty is summed both ways.
+  template <bool LIVE = false, class TP, class LS>
+  __device__ static double cost2(const KArgs& a, TP Q, TP R, TP tab,
+                                 const double* x, const double* u, const double* g,
+                                 const LS& lam, size_t ls, double mu, bool par, unsigned long long live = ~0ull) {
+    static_assert(!QUAD, "par_cval puts the quadratic term last");
+    double sc = 0.0, cc = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { double e = x[i] - g[i]; sc += (e * Q[i * N + i]) * e; }
+#pragma unroll
+    for (int j = 0; j < M; ++j) cc += (R[j * M + j] * u[j]) * u[j];
+    double pp = 0.0, ll = 0.0, al = 0.0;
+    const bool box = boxed(a, x, u);
+    if (box) {
+      TP Cv = tab + a.C * (N + M);
+#pragma unroll
+      for (int i = 0; i < NBOX; ++i) {
+        const BoxRow<N, M> row{i};
+        const double l = lam_at(lam, ls, i);
+        const double f = l - mu * ((row.dot(x, u) + 0.0) + Cv[i]);
+        double lp = a.eq ? f : fmin(f, 0.0);
+        pp += lp * lp;
+        ll += l * l;
+        al += lp * lp - l * l;
+      }
+    }
+    const ZeroSums zs = zero_sums(x, u);
+    auto row = [&](int i, const Row& r) {
+      const double l = r.l;
+      const double f = l - mu * cval(a, tab, x, u, i, r, zs);
+      double lp = a.eq ? f : fmin(f, 0.0);
+      pp += lp * lp;
+      ll += l * l;
+      al += lp * lp - l * l;
+    };
+    if constexpr (LIVE) for_live(a, lam, ls, step_rows(a, live, box, x, u), row);
+    else for_rows(a, lam, ls, row, box ? NBOX : 0);
+    return par ? (sc + cc) + 0.5 / mu * al : sc + cc + 0.5 / mu * (pp - ll);
+  }
   // one column of parallel_cost / parallel_augmented_lagrangian_cost (constraints.h:558-580)
   template <bool LIVE = false, class TP, class LS>
   __device__ static double par_cost(const KArgs& a, TP Q, TP R, TP tab,
@@ -1592,6 +1640,12 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   // scalar cache, with the table in LDS the reads are issued rows ahead and return in order.  A table shared by all
   // nodes is staged once per kernel; per-node tables are staged node by node inside the roll-out.
   constexpr bool TLDS = QUAD && (ALILQR_TAB_LDS != 0);
+  // the two kinds of NEW_AL roll-out (trial, ladder column) as one instruction stream: 6-state model, no quadratic rows
+  // (the 4-state kernels spill twice as much with it at 4 and 8 lanes and lose 40 % there)
+  // the first ladder columns of a NEW_AL line search in the idle lanes of its last round of trials.  Not for wide groups:
+  // their first round is the last one, and every search would pay for columns that three in ten need.
+  constexpr bool AHEAD = NEWAL && (G > 1) && (G <= 8) && (ALILQR_LADDER_AHEAD != 0);
+  constexpr bool MERGE = NEWAL && !QUAD && (N > 4) && (ALILQR_MERGE_KINDS != 0);
   // Roll-outs skip rows that cannot contribute (below).  Measured on 4096 problems: lateral model with the reference's
   // ten-row table (two live rows) 73 -> 101 k solves/s, with rectangle rows 41 -> 51 k; 6-state tables with two to four
   // spare rows unchanged; quadratic tables (every row live) lose a third with the masked loop and keep the plain one.
@@ -2235,7 +2289,9 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           if constexpr (!LEGACY) {
             if (valid) {
               auto node_J = [&](const auto& lp) -> double {
-                if constexpr (NEWAL) {
+                if constexpr (MERGE) {
+                  return OPS::template cost2<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, kind == 2, live_rows);
+                } else if constexpr (NEWAL) {
                   if (kind == 2) return OPS::template par_cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
                   return OPS::template cost<LIVE>(a, rQ(t), rR(t), rC(t), x, u, R.g, lp, ES, mu, live_rows);
                 } else {
@@ -2256,7 +2312,9 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
             if (valid) {
               double xn[N];
               keep();
-              if constexpr (NEWAL) {
+              if constexpr (MERGE) {
+                MD::step2(mc, x, u, xn, kind == 2);
+              } else if constexpr (NEWAL) {
                 if (kind == 2) MD::par_step(mc, x, u, xn);
                 else MD::template step<false>(mc, x, u, xn);
               } else {
@@ -2303,7 +2361,9 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           if constexpr (!LEGACY) {
             if (TLDS && a.table_nodes > 1) stage_tables(H);
             auto node_J = [&](const auto& lp) -> double {
-              if constexpr (NEWAL) {
+              if constexpr (MERGE) {
+                return OPS::template cost2<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, kind == 2, live_rows);
+              } else if constexpr (NEWAL) {
                 if (kind == 2) return OPS::template par_cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
                 return OPS::template cost<LIVE>(a, rQ(H), rR(H), rC(H), x, zu, RA.g, lp, ES, mu, live_rows);
               } else {
@@ -2500,12 +2560,30 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         int kind = 0, sslot = -1;
         double alpha = 1.0;
         int uct = 2;                             // LEGACY: the trial whose accumulated controls this lane reads
+        bool is_trial = false;
+        int spec = 0;                            // NEW_AL: ladder columns run ahead in the spare lanes of the last round
         if (stage == ST_TRIALS) {
           const int j = r0 + gl + 1;             // trial number, 1-based
           valid = j <= ntrials;
+          is_trial = valid;
           if (LEGACY) { kind = (j != 1) ? 1 : 0; alpha = 1.0; uct = (valid && j >= 2) ? j : 2; }
           else alpha = alpha_of(j);
           sslot = valid ? store_slot(j) : -1;
+          if constexpr (AHEAD) {
+            // The ladder follows when every trial is rejected (new_al_ilqr.h:1045-1062) and reads nothing the trials
+            // write: its first columns are rolled out by the lanes the last round of trials leaves idle, and are
+            // used only if the search gets there.
+            const int nv = ntrials - r0;
+            if (nv <= G) {
+              spec = (G - nv < 5) ? G - nv : 5;
+              const int i = gl - nv;
+              if (i >= 0 && i < spec) {
+                valid = true; kind = 2;
+                alpha = alpha_of(ntrials + 1);
+                for (int q = 0; q < i; ++q) alpha /= 3.0;
+              }
+            }
+          }
         } else if (stage == ST_LADDER) {
           // five-wide ladder alpha, alpha/3, ... from alpha = 2^-10 (new_al_ilqr.h:818-898)
           const int i = r0 + gl;
@@ -2525,7 +2603,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         P3_STAMP(2)                                 /* the roll-out */
 
         if (stage == ST_TRIALS) {
-          const bool ok = valid && (J < old_cost);
+          const bool ok = (AHEAD ? is_trial : valid) && (J < old_cost);
           const int w = gfirst<G>(ok, lane);
           int nv = ntrials - r0; if (nv > G) nv = G;      // trials evaluated this round
           if (w >= 0) {
@@ -2554,6 +2632,24 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           } else if (NEWAL) {
             if (J_last >= old_cost) {
               stage = ST_LADDER; r0 = 0; have = false;
+              if constexpr (AHEAD) {
+                for (int g = 0; g < spec; ++g) {
+                  const double Jg = gbcast<G>(J, nv + g), ag = gbcast<G>(alpha, nv + g);
+                  if (!have || Jg < bestJ) { bestJ = Jg; bestA = ag; have = true; }   // first smallest wins
+                }
+                r0 = spec;
+                if (r0 >= 5) {
+                  n_trials += 5;
+                  if (!(bestJ >= old_cost)) {    // new_al_ilqr.h:1062
+                    replay_kind = 0; replay_alpha = bestA;
+                    cur_slot = SS - 1;
+                    win_trial = 0;
+                    stage = ST_REPLAY;
+                  } else {
+                    stage = ST_DONE;
+                  }
+                }
+              }
             } else {
               new_cost = J_last;                 // not comparable (NaN): nothing is accepted, nothing converged
               keep_old = true;
