@@ -1642,10 +1642,12 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   constexpr bool TLDS = QUAD && (ALILQR_TAB_LDS != 0);
   // the two kinds of NEW_AL roll-out (trial, ladder column) as one instruction stream: 6-state model, no quadratic rows
   // (the 4-state kernels spill twice as much with it at 4 and 8 lanes and lose 40 % there)
-  // the first ladder columns of a NEW_AL line search in the idle lanes of its last round of trials.  Not for wide groups:
-  // their first round is the last one, and every search would pay for columns that three in ten need.
-  constexpr bool AHEAD = NEWAL && (G > 1) && (G <= 8) && (ALILQR_LADDER_AHEAD != 0);
   constexpr bool MERGE = NEWAL && !QUAD && (N > 4) && (ALILQR_MERGE_KINDS != 0);
+  // the first ladder columns of a NEW_AL line search in the idle lanes of its last round of trials.  For groups of 16 and
+  // 32 lanes the first round is the last one and every search carries the columns that three in ten need: only where
+  // the two kinds share one instruction stream (the columns then cost no pass time: kinematic + rectangles at 16 lanes
+  // 64 k -> 73 k solves/s, 387 -> 317 us per iteration at light load; divergent kinds, 4-state model: 136 -> 171 us)
+  constexpr bool AHEAD = NEWAL && (G > 1) && (G <= 8 || MERGE) && (ALILQR_LADDER_AHEAD != 0);
   // Roll-outs skip rows that cannot contribute (below).  Measured on 4096 problems: lateral model with the reference's
   // ten-row table (two live rows) 73 -> 101 k solves/s, with rectangle rows 41 -> 51 k; 6-state tables with two to four
   // spare rows unchanged; quadratic tables (every row live) lose a third with the masked loop and keep the plain one.
