@@ -97,9 +97,10 @@ inline int launch_family(const KArgs& ka, int G, int waves, hipStream_t st, int 
     // and used for the 6-state kernels (FAST included) at 8 lanes and up and for the 4-state linear-table kernels at 16 lanes.
     constexpr bool six = Model<MODEL>::N > 4;
     const bool wanted = six ? (G >= 8) : (G == 16 && !is_quad(MODE));
-    const bool fits = wanted && nch <= 8 && tl + (size_t)2 * nch * 1024 <= 40 * 1024;
+    // (+ 512 bytes behind the buffers: one 8-byte word per lane, where the 6-state NEW_AL kernels keep their live-row look)
+    const bool fits = wanted && nch <= 8 && tl + (size_t)2 * nch * 1024 + 512 <= 40 * 1024;
     kt.rows_lds = fits ? block : 0;
-    if (fits) tl += (size_t)2 * nch * 1024;
+    if (fits) tl += (size_t)2 * nch * 1024 + 512;
   }
   kt.lds_bytes = (int)tl;
   if constexpr (MODE != ALILQR_MODE_LEGACY) {

@@ -108,6 +108,9 @@ __device__ __forceinline__ ltab as_ltab(const double* p) {
 #ifndef ALILQR_TAB_LDS
 #define ALILQR_TAB_LDS 1
 #endif
+#ifndef ALILQR_LIVE_LDS
+#define ALILQR_LIVE_LDS 1
+#endif
 #ifndef ALILQR_MERGE_KINDS
 #define ALILQR_MERGE_KINDS 1
 #endif
@@ -1674,7 +1677,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   const int rows_lim = RLDS ? a.rows_lds : 0;                      // doubles of the block
   const int rows_nch = (rows_lim + CHD - 1) / CHD;                 // chunks per node
   const int rows_off = TLDS ? ((cw + N * N + M * M + 1) & ~1) : 0;  // first double of the buffers (16-byte aligned)
-  (void)ALILQR_CHK(!RLDS || (size_t)(rows_off + 2 * rows_nch * 128) * sizeof(double) <= (size_t)a.lds_bytes, 17);
+  (void)ALILQR_CHK(!RLDS || (size_t)(rows_off + 2 * rows_nch * 128 + 64) * sizeof(double) <= (size_t)a.lds_bytes, 17);
 
   // goal list of problem q (clamped: idle groups still form addresses)
   auto goal_of = [&](int q) -> const double* {
@@ -1960,7 +1963,10 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         // (4-state kernels; the 6-state ones look on every trip: the two more registers of the kept mask cost them
         //  7 to 12 %)
         constexpr bool KEEP = N <= 4;
-        if (p >= 0 && (!KEEP || (phase == PH_LIN && (outer_start || tables_changed)))) {
+        // 6-state kernels with the multiplier buffers in LDS keep the look there, one word per lane behind the buffers
+        constexpr bool KEEPL = !KEEP && RLDS && (ALILQR_LIVE_LDS != 0);
+        unsigned long long* const live_slot = reinterpret_cast<unsigned long long*>(lds_pool + rows_off + (size_t)2 * rows_nch * 128) + lane;
+        if (p >= 0 && ((!KEEP && !KEEPL) || (phase == PH_LIN && (outer_start || tables_changed)))) {
           unsigned long long lm = 0ull;
           for (int t = gl; t <= H; t += G) {
             const double* lp = rec(t) + (size_t)RL::rl * ES;
@@ -1972,6 +1978,9 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
             }
           }
           live_g = lm;                                  // this lane's nodes; the union over the wave is formed below
+          if constexpr (KEEPL) *live_slot = lm;
+        } else if (KEEPL) {
+          live_g = (p >= 0) ? *live_slot : 0ull;
         } else if (!KEEP) {
           live_g = 0ull;
         }
