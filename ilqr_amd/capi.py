@@ -135,7 +135,8 @@ LIB_PATH = os.environ.get("ALILQR_LIB") or os.path.join(os.path.dirname(os.path.
 EXPORTS = ("alilqr_abi_version", "alilqr_last_error", "alilqr_device_count", "alilqr_default_params",
            "alilqr_workspace_bytes", "alilqr_solve_batch", "alilqr_solve_batch_multistart", "alilqr_solve_batch_ex",
            "alilqr_linearize_batch", "alilqr_node_aux_batch", "alilqr_constraints_batch",
-           "alilqr_solve_batches", "alilqr_release", "alilqr_solve_batch_noalloc", "alilqr_static_scratch_bytes", "alilqr_set_tuning")
+           "alilqr_solve_batches", "alilqr_release", "alilqr_solve_batch_noalloc", "alilqr_static_scratch_bytes", "alilqr_set_tuning",
+           "alilqr_lanes_for")
 
 
 class LibraryMissing(RuntimeError):
@@ -164,6 +165,8 @@ def load_library():
     lib.alilqr_default_params.argtypes = [C.c_int32, C.POINTER(Params)]
     lib.alilqr_workspace_bytes.restype = C.c_int64
     lib.alilqr_workspace_bytes.argtypes = [C.POINTER(Problem)]
+    lib.alilqr_lanes_for.restype = C.c_int32
+    lib.alilqr_lanes_for.argtypes = [C.POINTER(Problem)]
     lib.alilqr_solve_batch.restype = C.c_int32
     lib.alilqr_solve_batch.argtypes = [C.POINTER(Problem)] + [C.c_void_p] * 17
     lib.alilqr_solve_batch_multistart.restype = C.c_int32

@@ -169,6 +169,12 @@ int pick_group(const alilqr_problem* p) {
   // problems in one launch 34.5 k solves/s at 8 lanes, 33.0 k at 4 (16 lanes 32.0 k), six such batches in one call
   // 66.7 k at 4 lanes, 60.8 k at 8, 50 k at 16; kinematic model H = 50: 8192 problems 40.6 k at 8 lanes (16 lanes
   // 27.4 k, 4 lanes 29.6 k), 16384 problems 49.4 k at 4 lanes (8 lanes 40.9 k).
+  // The dynamic model, whose 6 x 6 sweep is the largest share of an iteration, one lane per problem from 65536 problems
+  // (the wave-wide line search spreads the trials of a lane's problem over the wave, so a single lane does not roll out
+  // its trials one after the other).  H = 100, one launch: 65536 problems 61.5 k solves/s at 1 lane against 59.4 k at 4,
+  // 131072 73.0 k / 68.7 k, 262144 81.6 k / 74.4 k; 32768 43.4 k / 48.9 k.  The kinematic model (H = 50) keeps 4 lanes at
+  // every size (262144 problems: 58.3 k at 1 lane, 61.7 k at 4).
+  if (p->mode == ALILQR_MODE_LEGACY && p->model == ALILQR_MODEL_DYN && p->batch >= 65536) return 1;
   if (p->mode == ALILQR_MODE_LEGACY && p->batch >= 16384) return 4;
   if (p->mode == ALILQR_MODE_LEGACY && p->batch >= 8192) return 8;
   // The 4-state NEW_AL model from 262144 problems: 4 lanes.  One launch of that size runs as fast at 4 lanes as at 16
@@ -489,6 +495,13 @@ int64_t alilqr_workspace_bytes(const alilqr_problem* p) {
   if (rc != ALILQR_OK) return rc;
   /* NEW_AL: sized for a solve with rectangle obstacles (the larger record) */
   return (int64_t)make_plan(p, d, p->mode == ALILQR_MODE_NEW_AL).total;
+}
+
+int32_t alilqr_lanes_for(const alilqr_problem* p) {
+  Dims d;
+  int32_t rc = check_problem(p, &d);
+  if (rc != ALILQR_OK) return rc;
+  return pick_group(p);
 }
 
 int32_t alilqr_solve_batch(const alilqr_problem* p,

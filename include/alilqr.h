@@ -140,6 +140,11 @@ int32_t alilqr_default_params(int32_t mode, alilqr_params* out);
 /* Upper bound of the bytes of device scratch a solve of this descriptor will hold. */
 int64_t alilqr_workspace_bytes(const alilqr_problem* p);
 
+/* Lanes per problem (1, 4, 8, 16 or 32) a solve of this descriptor will run with, or a negative alilqr_status.  For
+ * alilqr_solve_batches pass a descriptor whose batch is the total over the call.  Diagnostic (profiling tools run a
+ * single batch at the width a many-batch call uses); no counterpart in the reference. */
+int32_t alilqr_lanes_for(const alilqr_problem* p);
+
 /*
  * Solve a batch.  Stands in for
  *   ILQR(nodes).optimize(max_iters, tol)        cilqr/ilqr.py:151-175

@@ -72,6 +72,23 @@ def test_bad_descriptors_are_rejected_before_any_device_work():
     assert call(empty) == 0                               # an empty batch is valid and touches nothing
 
 
+def test_lanes_for_answers_without_a_device():
+    """The lane width the library will use is a function of the descriptor alone: small LEGACY models keep 32 lanes at
+    any batch size, the other generations narrow their groups as the batch grows; a bad descriptor is an error."""
+    lib = capi.load_library()
+    width = lambda *a, **k: lib.alilqr_lanes_for(C.byref(capi.make_problem(*a, **k)))
+    assert width("lat", "legacy", 50, 4096, 1.0, 0.1, v=10.0) == 32
+    assert width("lat", "legacy", 50, 81920, 1.0, 0.1, v=10.0) == 32
+    seen = [width("dyn_mid", "fast", 100, b, 3.0, 0.1, v=10.0, k=0.001, c=18) for b in (1024, 8192, 16384)]
+    assert seen == [16, 8, 4]
+    for b in (64, 4096, 16384, 65536, 327680):
+        assert width("dyn", "legacy", 100, b, 3.0, 0.1, v=10.0, k=0.001) in (1, 4, 8, 16, 32)
+        assert width("new_bicycle", "new_al", 50, b, 3.0, 0.1, v=10.0, k=0.001, c=14) in (8, 16)
+    bad = capi.make_problem("lat", "legacy", 50, 4, 1.0, 0.1, v=10.0)
+    bad.c = 7
+    assert lib.alilqr_lanes_for(C.byref(bad)) == capi.E_ARG
+
+
 def test_no_cpu_fallback_without_a_device():
     import torch
     if torch.cuda.is_available():

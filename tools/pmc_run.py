@@ -6,13 +6,13 @@ the GPU, so that every solve_kernel dispatch of a rocprofv3 pass is the same lau
 Prints one JSON line: configuration, batch, launches, mean launch time (HIP events), iteration / roll-out totals of a
 launch and its algorithmic operation / byte counts (the figures bench.py's roofline uses).
 """
-import argparse, json, os, sys
+import argparse, ctypes as C, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 import bench
-from ilqr_amd import batch
+from ilqr_amd import batch, capi
 
 
 def main():
@@ -23,6 +23,13 @@ def main():
     a = ap.parse_args()
     B = a.batch or bench.CONFIGS[a.config]["batch"]
     prob, kw = bench.make_workload(a.config, B, 0)
+    # the lane width of the bench's library call: configurations without optional inputs go through alilqr_solve_batches,
+    # 20 batches per call, and the library picks the width for the call's total
+    if not kw and a.config not in ("3", "5"):
+        call = type(prob[0]).from_buffer_copy(prob[0]); call.batch = B * 20
+        lanes = capi.load_library().alilqr_lanes_for(C.byref(call))
+        assert lanes > 0, capi.last_error()
+        capi.set_tuning(lanes=lanes)
     sv = batch.BatchSolver(*prob, extras=False, **kw)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.launches)]
     for e0, e1 in ev:
