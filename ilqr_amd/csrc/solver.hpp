@@ -108,12 +108,33 @@ __device__ __forceinline__ ltab as_ltab(const double* p) {
 #ifndef ALILQR_TAB_LDS
 #define ALILQR_TAB_LDS 1
 #endif
+#ifndef ALILQR_WAVE_COPY
+#define ALILQR_WAVE_COPY 1
+#endif
 #ifndef ALILQR_LIVE_LDS
 #define ALILQR_LIVE_LDS 1
 #endif
 #ifndef ALILQR_MERGE_KINDS
 #define ALILQR_MERGE_KINDS 1
 #endif
+// the value lane `l` of the wave holds (l the same in every lane).  Host builds run the groups of a wave one after the
+// other: only the own group's lane 0 is ever asked for there, and the caller's own value is that value.
+__device__ __forceinline__ int wave_int(int v, int l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_readlane(v, l);
+#else
+  (void)l; return v;
+#endif
+}
+__device__ __forceinline__ const double* wave_ptr(const double* p, int l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)a, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(a >> 32), l);
+  return (const double*)(((unsigned long long)hi << 32) | lo);
+#else
+  (void)l; return p;
+#endif
+}
 // a value that is the same in every lane, as a scalar (host builds: the value)
 __device__ __forceinline__ unsigned long long wave_uniform(unsigned long long m) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -876,10 +897,26 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
   // lam <- min(lam - mu c, 0)  (cilqr/constraints.py:106-110; c is the value cached by max_violation at the same point)
   __device__ static void update_lambda(const KArgs& a, ctab tab, const double* x, const double* u,
                                        double* lam, size_t ls, double mu) {
-    for (int i = 0; i < a.C; ++i) {
-      double c = cval(a, tab, x, u, i);
-      const double f = lam[i * ls] - mu * c;
-      lam[i * ls] = a.eq ? f : fmin(f, 0.0);
+    // Eight rows at a time: their multipliers are loaded together, then the rows are updated and stored.  (A load behind
+    // a store of the same array waits for the store - vector memory returns in order and the two may alias for all the
+    // compiler knows - so row by row every row costs a round trip to memory.)
+    constexpr int CH = 8;
+    for (int i0 = 0; i0 < a.C; i0 += CH) {
+      double l[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) l[k] = lam[(size_t)((i0 + k < a.C) ? i0 + k : a.C - 1) * ls];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int i = i0 + k;
+        if (i < a.C) {
+          double c = cval(a, tab, x, u, i);
+          const double f = l[k] - mu * c;
+          const double nl = a.eq ? f : fmin(f, 0.0);
+          // a multiplier that keeps its bits (a row that stays inactive stays at +0) is not written again: the phase that
+          // follows waits for these stores to complete, and they are single 8-byte pieces of separate lines
+          if (__double_as_longlong(nl) != __double_as_longlong(l[k])) lam[(size_t)i * ls] = nl;
+        }
+      }
     }
   }
 };
@@ -1357,8 +1394,10 @@ struct NewAlOps {
                                        double* lam, size_t ls, double mu, unsigned long long live = ~0ull) {
     auto row = [&](int i) {
       double c = cval(a, tab, x, u, i, lam, ls);
-      const double f = lam[i * ls] - mu * c;
-      lam[i * ls] = a.eq ? f : fmin(f, 0.0);        // constraints.h:878-887
+      const double l = lam[i * ls];
+      const double f = l - mu * c;
+      const double nl = a.eq ? f : fmin(f, 0.0);    // constraints.h:878-887
+      if (__double_as_longlong(nl) != __double_as_longlong(l)) lam[i * ls] = nl;   // (unchanged bits are not written again)
     };
     if constexpr (LIVE) {
       for (unsigned long long m = step_rows(a, live, false, x, u); m != 0ull; m &= m - 1ull) row(__builtin_ctzll(m));
@@ -1645,6 +1684,8 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
   constexpr bool TLDS = QUAD && (ALILQR_TAB_LDS != 0);
   // the two kinds of NEW_AL roll-out (trial, ladder column) as one instruction stream: 6-state model, no quadratic rows
   // (the 4-state kernels spill twice as much with it at 4 and 8 lanes and lose 40 % there)
+  // FAST: the returned pair (x, u of the last iteration that did not end an inner loop) is copied by the whole wave
+  constexpr bool WCOPY = (MODE == ALILQR_MODE_FAST) && (G < 32) && (ALILQR_WAVE_COPY != 0);
   constexpr bool MERGE = NEWAL && !QUAD && (N > 4) && (ALILQR_MERGE_KINDS != 0);
   // the first ladder columns of a NEW_AL line search in the idle lanes of its last round of trials.  For groups of 16 and
   // 32 lanes the first round is the last one and every search carries the columns that three in ten need: only where
@@ -2701,6 +2742,9 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
       }
       P3_STAMP(4)                                   /* loop end -> MARK(4) */
       PROF_MARK(4)
+     bool wc_need = false;                       // FAST: this group's returned pair is to be copied behind the phase (WCOPY)
+     const double* wc_src = nullptr;
+     int wc_p = 0;
      if (p >= 0 && stage == ST_DONE) {
       if (win_trial >= 0) cur_par = np_;
       __threadfence_block();
@@ -2743,10 +2787,15 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
           // The pair to return is the trajectory of the last iteration that did not end the inner loop.  It sits in
           // the parity this iteration's candidates were NOT written to (or is the one just accepted), so it is
           // still whole; the next outer iteration's first line search will overwrite it.
-          double* const o_xo = ALILQR_COLD(x_out);
-          double* const o_uo = ALILQR_COLD(u_out);
-          for (int e = gl; e < XS; e += G) o_xo[(size_t)p * XS + e] = *trj_at(xo_par, e, xo_slot);
-          for (int e = gl; e < US; e += G) o_uo[(size_t)p * US + e] = *trj_at(xo_par, XS + e, xo_slot);
+          if constexpr (WCOPY) {
+            // noted for the copy by the whole wave behind this phase
+            wc_need = true; wc_src = trj_at(xo_par, 0, xo_slot); wc_p = p;
+          } else {
+            double* const o_xo = ALILQR_COLD(x_out);
+            double* const o_uo = ALILQR_COLD(u_out);
+            for (int e = gl; e < XS; e += G) o_xo[(size_t)p * XS + e] = *trj_at(xo_par, e, xo_slot);
+            for (int e = gl; e < US; e += G) o_uo[(size_t)p * US + e] = *trj_at(xo_par, XS + e, xo_slot);
+          }
           xo_pend = false;
         }
       }
@@ -2855,6 +2904,29 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
         p = -1;
       }
       phase = PH_LIN;
+     }
+     if constexpr (WCOPY) {
+       // The returned pair of the groups whose inner loop ended in this trip, copied by all 64 lanes, one group after the
+       // other: whole 512-byte pieces per store instruction instead of G x 8 bytes per group (a narrow group would issue
+       // (XS + US) / G loads and stores of its own, and the next phase waits for the stores).
+       unsigned long long m = wave_uniform(__ballot(wc_need && gl == 0));
+       if (m != 0ull) {
+         double* const o_xo = ALILQR_COLD(x_out);
+         double* const o_uo = ALILQR_COLD(u_out);
+         while (m != 0ull) {
+           const int l = __builtin_ctzll(m);
+           m &= m - 1ull;
+           const double* const src = wave_ptr(wc_src, l);
+           const int pp = wave_int(wc_p, l);
+#if defined(__HIP_DEVICE_COMPILE__)
+           const int e0 = lane, es = 64;
+#else
+           const int e0 = gl, es = G;            // host builds: a group's lanes are all there is of the wave
+#endif
+           for (int e = e0; e < XS; e += es) o_xo[(size_t)pp * XS + e] = src[e];
+           for (int e = e0; e < US; e += es) o_uo[(size_t)pp * US + e] = src[XS + e];
+         }
+       }
      }
       PROF_MARK(5)
   }

@@ -56,6 +56,7 @@ template <class T> inline T __shfl(T v, int src) {
   if (src < base || src >= base + G) { std::fprintf(stderr, "host emulation: cross-group __shfl (LEGACY line search) is not emulated\n"); std::abort(); }
   return __shfl(v, src - base, G);
 }
+inline long long __double_as_longlong(double d) { long long r; std::memcpy(&r, &d, sizeof r); return r; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 // ballot over the group only, placed at the group's bit positions inside the wave
 inline unsigned long long __ballot(bool p) {
