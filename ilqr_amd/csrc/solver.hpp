@@ -895,6 +895,9 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
   __device__ static double combine_violation(double acc, double node) { return (node > acc || node != node) ? node : acc; }
   __device__ static double violation_init() { return -1.0; }
   // lam <- min(lam - mu c, 0)  (cilqr/constraints.py:106-110; c is the value cached by max_violation at the same point)
+  // TWO: values of a chunk before its stores (narrow groups, where the update is a larger share: box + linear rows
+  // H = 100 at 4 lanes +2.5 ... +4.7 %; the 16-lane kernels lose 4 to 5 % with it and keep the row-by-row stores)
+  template <bool TWO = false>
   __device__ static void update_lambda(const KArgs& a, ctab tab, const double* x, const double* u,
                                        double* lam, size_t ls, double mu) {
     // Eight rows at a time: their multipliers are loaded together, then the rows are updated and stored.  (A load behind
@@ -905,16 +908,31 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
       double l[CH];
 #pragma unroll
       for (int k = 0; k < CH; ++k) l[k] = lam[(size_t)((i0 + k < a.C) ? i0 + k : a.C - 1) * ls];
+      // A multiplier that keeps its bits (a row that stays inactive stays at +0) is not written again: what follows waits
+      // for these stores to complete, and they are single 8-byte pieces of separate lines.
+      if constexpr (TWO) {
+        // all eight new values first (table rows of the clamped index: the loads of a row then never follow a store),
+        // then the stores
+        double nl[CH];
 #pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        const int i = i0 + k;
-        if (i < a.C) {
-          double c = cval(a, tab, x, u, i);
+        for (int k = 0; k < CH; ++k) {
+          const double c = cval(a, tab, x, u, (i0 + k < a.C) ? i0 + k : a.C - 1);
           const double f = l[k] - mu * c;
-          const double nl = a.eq ? f : fmin(f, 0.0);
-          // a multiplier that keeps its bits (a row that stays inactive stays at +0) is not written again: the phase that
-          // follows waits for these stores to complete, and they are single 8-byte pieces of separate lines
-          if (__double_as_longlong(nl) != __double_as_longlong(l[k])) lam[(size_t)i * ls] = nl;
+          nl[k] = a.eq ? f : fmin(f, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+          if (i0 + k < a.C && __double_as_longlong(nl[k]) != __double_as_longlong(l[k])) lam[(size_t)(i0 + k) * ls] = nl[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int i = i0 + k;
+          if (i < a.C) {
+            double c = cval(a, tab, x, u, i);
+            const double f = l[k] - mu * c;
+            const double nl = a.eq ? f : fmin(f, 0.0);
+            if (__double_as_longlong(nl) != __double_as_longlong(l[k])) lam[(size_t)i * ls] = nl;
+          }
         }
       }
     }
@@ -2839,6 +2857,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
                 load_node(t, x, u);
                 double* lp = rec(t) + (size_t)RL::rl * ES;
                 if constexpr (LIVE) OPS::template update_lambda<true>(a, tabC(t), x, u, lp, ES, mu, live_rows);
+                else if constexpr (MODE == ALILQR_MODE_FAST) OPS::template update_lambda<(G <= 8)>(a, tabC(t), x, u, lp, ES, mu);
                 else OPS::update_lambda(a, tabC(t), x, u, lp, ES, mu);
                 if (LEGACY) {
 #pragma unroll
