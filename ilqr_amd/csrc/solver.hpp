@@ -108,6 +108,10 @@ __device__ __forceinline__ ltab as_ltab(const double* p) {
 #ifndef ALILQR_TAB_LDS
 #define ALILQR_TAB_LDS 1
 #endif
+// FAST groups of 4 lanes and fewer keep the trajectories of the first ALILQR_FAST_KEEP trials only (0: of all)
+#ifndef ALILQR_FAST_KEEP
+#define ALILQR_FAST_KEEP 2
+#endif
 #ifndef ALILQR_WAVE_COPY
 #define ALILQR_WAVE_COPY 1
 #endif
@@ -2280,6 +2284,10 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
       // rolled out once more into the spare slot SS-1: same code, same inputs, same bits.
       auto store_slot = [&](int j) -> int {
         if (LEGACY) return (j == 1) ? 0 : (j == 2) ? 1 : (j == ntrials) ? 2 : -1;
+        // FAST at 4 lanes: the first trial wins four searches in five and the phase behind the roll-outs waits for their
+        // stores; trials 3 and 4 keep nothing and are rolled out again when they win (box + linear rows H = 100 +3 to +4 %,
+        // box rows +0.3 %; keeping trial 1 only: +3 % / -4 %)
+        if constexpr (MODE == ALILQR_MODE_FAST && G <= 4 && ALILQR_FAST_KEEP > 0) return (j <= ALILQR_FAST_KEEP) ? j - 1 : -1;
         return (j <= SS - 1) ? j - 1 : -1;
       };
       // roll out one trial.  kind 0: closed loop, step alpha (Python generations: (u + alpha k) + K dx;
