@@ -108,9 +108,16 @@ __device__ __forceinline__ ltab as_ltab(const double* p) {
 #ifndef ALILQR_TAB_LDS
 #define ALILQR_TAB_LDS 1
 #endif
-// FAST groups of 4 lanes and fewer keep the trajectories of the first ALILQR_FAST_KEEP trials only (0: of all)
+// FAST groups of ALILQR_FAST_KEEP_G lanes and fewer keep the trajectories of the first ALILQR_FAST_KEEP trials only (0: of all);
+// groups of ALILQR_FAST_TWO_G lanes and fewer form a chunk's new multipliers before its stores
 #ifndef ALILQR_FAST_KEEP
 #define ALILQR_FAST_KEEP 2
+#endif
+#ifndef ALILQR_FAST_TWO_G
+#define ALILQR_FAST_TWO_G 4
+#endif
+#ifndef ALILQR_FAST_KEEP_G
+#define ALILQR_FAST_KEEP_G 8
 #endif
 #ifndef ALILQR_WAVE_COPY
 #define ALILQR_WAVE_COPY 1
@@ -899,8 +906,8 @@ struct NodeOps<MODEL, ALILQR_MODE_FAST> {
   __device__ static double combine_violation(double acc, double node) { return (node > acc || node != node) ? node : acc; }
   __device__ static double violation_init() { return -1.0; }
   // lam <- min(lam - mu c, 0)  (cilqr/constraints.py:106-110; c is the value cached by max_violation at the same point)
-  // TWO: values of a chunk before its stores (narrow groups, where the update is a larger share: box + linear rows
-  // H = 100 at 4 lanes +2.5 ... +4.7 %; the 16-lane kernels lose 4 to 5 % with it and keep the row-by-row stores)
+  // TWO: values of a chunk before its stores (4-lane groups, where the update is a larger share: box + linear rows
+  // H = 100 +2.5 ... +4.7 %; the 8- and 16-lane kernels lose 4 to 8 % with it and keep the row-by-row stores)
   template <bool TWO = false>
   __device__ static void update_lambda(const KArgs& a, ctab tab, const double* x, const double* u,
                                        double* lam, size_t ls, double mu) {
@@ -2284,10 +2291,10 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
       // rolled out once more into the spare slot SS-1: same code, same inputs, same bits.
       auto store_slot = [&](int j) -> int {
         if (LEGACY) return (j == 1) ? 0 : (j == 2) ? 1 : (j == ntrials) ? 2 : -1;
-        // FAST at 4 lanes: the first trial wins four searches in five and the phase behind the roll-outs waits for their
-        // stores; trials 3 and 4 keep nothing and are rolled out again when they win (box + linear rows H = 100 +3 to +4 %,
-        // box rows +0.3 %; keeping trial 1 only: +3 % / -4 %)
-        if constexpr (MODE == ALILQR_MODE_FAST && G <= 4 && ALILQR_FAST_KEEP > 0) return (j <= ALILQR_FAST_KEEP) ? j - 1 : -1;
+        // FAST at 4 and 8 lanes: the first trial wins four searches in five and the phase behind the roll-outs waits for
+        // their stores; trials 3 and up keep nothing and are rolled out again when they win (box + linear rows H = 100 +3
+        // to +7 %, box rows -2 to +1 %; keeping trial 1 only: +3 % / -4 %; 16 lanes: box rows -9 to -14 %, not there)
+        if constexpr (MODE == ALILQR_MODE_FAST && G <= ALILQR_FAST_KEEP_G && ALILQR_FAST_KEEP > 0) return (j <= ALILQR_FAST_KEEP) ? j - 1 : -1;
         return (j <= SS - 1) ? j - 1 : -1;
       };
       // roll out one trial.  kind 0: closed loop, step alpha (Python generations: (u + alpha k) + K dx;
@@ -2865,7 +2872,7 @@ __global__ __launch_bounds__(64, (MINW ? MINW : (Model<MODEL>::N <= 4 ? ALILQR_M
                 load_node(t, x, u);
                 double* lp = rec(t) + (size_t)RL::rl * ES;
                 if constexpr (LIVE) OPS::template update_lambda<true>(a, tabC(t), x, u, lp, ES, mu, live_rows);
-                else if constexpr (MODE == ALILQR_MODE_FAST) OPS::template update_lambda<(G <= 8)>(a, tabC(t), x, u, lp, ES, mu);
+                else if constexpr (MODE == ALILQR_MODE_FAST) OPS::template update_lambda<(G <= ALILQR_FAST_TWO_G)>(a, tabC(t), x, u, lp, ES, mu);
                 else OPS::update_lambda(a, tabC(t), x, u, lp, ES, mu);
                 if (LEGACY) {
 #pragma unroll
